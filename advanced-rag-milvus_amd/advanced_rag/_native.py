@@ -1,0 +1,289 @@
+"""ctypes binding of libhbmrag.so (C ABI: include/hbmrag.h).
+
+The library is the product's compute path; there is no Python or CPU fallback.
+If the shared object is missing or no HIP device is present, loading or
+`ShardHandle(...)` raises — callers fail loudly instead of degrading.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+HR_F32, HR_F16 = 0, 1
+HR_METRIC_IP, HR_METRIC_COSINE = 0, 1
+HR_METHOD_SEMANTIC, HR_METHOD_SPARSE, HR_METHOD_DOMAIN = 1, 2, 4
+HR_MAX_TOPK = 256
+HR_N_PHASES = 9
+PHASE_NAMES = ("prep", "dense_scan", "group_select", "refine", "topk",
+               "sparse_scan", "sparse_select", "sparse_refine", "sparse_topk")
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhbmrag.so")
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class HbmRagError(RuntimeError):
+    """HIP/runtime failure reported by libhbmrag (status 2..5)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libhbmrag status {status}: {message}")
+        self.status = status
+
+
+_c = ctypes
+_SIGNATURES = {
+    "hr_version": (_c.c_int, []),
+    "hr_create": (_c.c_int, [_c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int64, _c.POINTER(_c.c_void_p)]),
+    "hr_destroy": (None, [_c.c_void_p]),
+    "hr_last_error": (_c.c_char_p, [_c.c_void_p]),
+    "hr_set_row_offset": (_c.c_int, [_c.c_void_p, _c.c_int64]),
+    "hr_reserve": (_c.c_int, [_c.c_void_p, _c.c_int64]),
+    "hr_add_dense": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64]),
+    "hr_add_dense_raw": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64]),
+    "hr_add_dense_raw_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
+    "hr_add_sparse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64]),
+    "hr_finalize": (_c.c_int, [_c.c_void_p]),
+    "hr_num_rows": (_c.c_int64, [_c.c_void_p]),
+    "hr_num_sparse_rows": (_c.c_int64, [_c.c_void_p]),
+    "hr_device_bytes": (_c.c_int64, [_c.c_void_p]),
+    "hr_dense_scan_bytes": (_c.c_int64, [_c.c_void_p]),
+    "hr_search_dense": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                   _c.c_void_p]),
+    "hr_search_sparse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int,
+                                    _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_fuse_rrf": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int,
+                               _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_void_p,
+                               _c.c_void_p, _c.c_void_p]),
+    "hr_search_dense_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                       _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_search_sparse_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64,
+                                        _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                        _c.c_void_p]),
+    "hr_fuse_rrf_dev": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int,
+                                   _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_int, _c.c_void_p,
+                                   _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_merge_topk_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                     _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_set_profiling": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "hr_last_kernel_ms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """Load libhbmrag.so (building nothing: run __graft_entry__.build() or `make` first)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or os.environ.get("HBMRAG_LIB", LIB_PATH)
+        if not os.path.exists(p):
+            raise FileNotFoundError(
+                f"{p} not found: build it with `make -C advanced-rag-milvus_amd` "
+                "(or __graft_entry__.build()); there is no CPU fallback")
+        try:
+            # torch ships its own libamdhip64 with the same soname; import it first
+            # so both sides share ONE HIP runtime (device pointers interoperate).
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the library itself
+            pass
+        L = ctypes.CDLL(p)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if path is None:
+            _lib = L
+        return L
+
+
+def _vp(a) -> Optional[ctypes.c_void_p]:
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(ctypes.c_void_p)
+    return ctypes.c_void_p(int(a))  # raw device pointer (e.g. tensor.data_ptr())
+
+
+class ShardHandle:
+    """One GPU's shard: dense tiles + sparse postings, owned by libhbmrag."""
+
+    def __init__(self, dim: int, dtype: int = HR_F16, metric: int = HR_METRIC_COSINE, sparse_dim: int = 0,
+                 device: int = 0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        self.dim, self.dtype, self.metric, self.sparse_dim, self.device = dim, dtype, metric, sparse_dim, device
+        rc = self._lib.hr_create(device, dim, dtype, metric, sparse_dim, ctypes.byref(self._h))
+        if rc != 0:
+            msg = (self._lib.hr_last_error(None) or b"").decode()
+            self._h = ctypes.c_void_p()
+            self._raise(rc, msg)
+
+    # -- error mapping: HR_EINVAL -> ValueError (as the reference raises for bad
+    #    collections/shapes, indexing.py:466-467); everything else -> HbmRagError
+    def _raise(self, rc: int, msg: Optional[str] = None):
+        if msg is None:
+            msg = (self._lib.hr_last_error(self._h) or b"").decode()
+        if rc == 1:
+            raise ValueError(msg)
+        raise HbmRagError(rc, msg)
+
+    def _check(self, rc: int):
+        if rc != 0:
+            self._raise(rc)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.hr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ingest
+    def set_row_offset(self, first_row: int):
+        self._check(self._lib.hr_set_row_offset(self._h, first_row))
+
+    def reserve(self, n_rows: int):
+        self._check(self._lib.hr_reserve(self._h, n_rows))
+
+    def add_dense(self, rows: np.ndarray):
+        rows = np.ascontiguousarray(rows)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise ValueError(f"rows must be [n,{self.dim}], got {rows.shape}")
+        if rows.dtype == np.float32 and self.dtype == HR_F16:
+            self._check(self._lib.hr_add_dense(self._h, _vp(rows), rows.shape[0]))
+        elif (rows.dtype == np.float16 and self.dtype == HR_F16) or (rows.dtype == np.float32 and self.dtype == HR_F32):
+            self._check(self._lib.hr_add_dense_raw(self._h, _vp(rows), rows.shape[0]))
+        else:
+            raise ValueError(f"cannot ingest {rows.dtype} rows into this shard")
+
+    def add_dense_dev(self, d_ptr: int, n: int, stream: int = 0):
+        self._check(self._lib.hr_add_dense_raw_dev(self._h, _vp(d_ptr), n, _vp(stream) if stream else None))
+
+    def add_sparse(self, indptr: np.ndarray, indices: np.ndarray, values: np.ndarray):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        self._check(self._lib.hr_add_sparse(self._h, _vp(indptr), _vp(indices), _vp(values), indptr.shape[0] - 1))
+
+    def finalize(self):
+        self._check(self._lib.hr_finalize(self._h))
+
+    @property
+    def num_rows(self) -> int:
+        return int(self._lib.hr_num_rows(self._h))
+
+    @property
+    def num_sparse_rows(self) -> int:
+        return int(self._lib.hr_num_sparse_rows(self._h))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._lib.hr_device_bytes(self._h))
+
+    @property
+    def dense_scan_bytes(self) -> int:
+        return int(self._lib.hr_dense_scan_bytes(self._h))
+
+    # -- search, host buffers
+    def search_dense(self, q: np.ndarray, k: int, rowmask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        q = np.ascontiguousarray(np.atleast_2d(q), dtype=np.float32)
+        if q.shape[1] != self.dim:
+            raise ValueError(f"query dim {q.shape[1]} != shard dim {self.dim}")
+        B = q.shape[0]
+        ids = np.empty((B, k), dtype=np.int64)
+        sc = np.empty((B, k), dtype=np.float32)
+        m = None if rowmask is None else np.ascontiguousarray(rowmask, dtype=np.uint8)
+        self._check(self._lib.hr_search_dense(self._h, _vp(q), B, k, _vp(m), _vp(ids), _vp(sc)))
+        return ids, sc
+
+    def search_sparse(self, queries: Sequence[Tuple[Sequence[int], Sequence[float]]], k: int,
+                      drop_ratio: float = 0.0, rowmask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+        B = len(queries)
+        indptr = np.zeros(B + 1, dtype=np.int64)
+        for b, (qi, _) in enumerate(queries):
+            indptr[b + 1] = indptr[b] + len(qi)
+        idx = np.concatenate([np.asarray(qi, dtype=np.int32) for qi, _ in queries]) if indptr[-1] else np.zeros(0, np.int32)
+        val = np.concatenate([np.asarray(qv, dtype=np.float32) for _, qv in queries]) if indptr[-1] else np.zeros(0, np.float32)
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=np.float32)
+        ids = np.empty((B, k), dtype=np.int64)
+        sc = np.empty((B, k), dtype=np.float32)
+        m = None if rowmask is None else np.ascontiguousarray(rowmask, dtype=np.uint8)
+        self._check(self._lib.hr_search_sparse(self._h, _vp(indptr), _vp(idx), _vp(val), B, k, float(drop_ratio),
+                                               _vp(m), _vp(ids), _vp(sc)))
+        return ids, sc
+
+    def fuse_rrf(self, ids_a, ids_b, ids_c=(), wa: float = 0.7, wb: float = 0.3, wc: float = 0.2, rrf_k: int = 60):
+        a = np.ascontiguousarray(ids_a, dtype=np.int64)
+        b = np.ascontiguousarray(ids_b, dtype=np.int64)
+        c = np.ascontiguousarray(ids_c, dtype=np.int64)
+        cap = max(len(a) + len(b) + len(c), 1)
+        oi = np.empty(cap, dtype=np.int64)
+        os_ = np.empty(cap, dtype=np.float64)
+        om = np.empty(cap, dtype=np.int32)
+        n = ctypes.c_int32(0)
+        self._check(self._lib.hr_fuse_rrf(self._h, _vp(a) if len(a) else None, len(a), _vp(b) if len(b) else None,
+                                          len(b), _vp(c) if len(c) else None, len(c), wa, wb, wc, rrf_k, _vp(oi),
+                                          _vp(os_), _vp(om), ctypes.byref(n)))
+        return oi[:n.value].copy(), os_[:n.value].copy(), om[:n.value].copy()
+
+    # -- search, device buffers (raw pointers; asynchronous on `stream`)
+    def search_dense_dev(self, d_q: int, B: int, k: int, d_ids: int, d_scores: int, d_flags: int = 0,
+                         d_rowmask: int = 0, stream: int = 0):
+        self._check(self._lib.hr_search_dense_dev(self._h, _vp(d_q), B, k, _vp(d_rowmask) if d_rowmask else None,
+                                                  _vp(d_ids), _vp(d_scores), _vp(d_flags) if d_flags else None,
+                                                  _vp(stream) if stream else None))
+
+    def search_sparse_dev(self, d_indptr: int, d_idx: int, d_val: int, B: int, nnz_total: int, max_q_nnz: int, k: int,
+                          d_ids: int, d_scores: int, d_flags: int = 0, d_rowmask: int = 0, stream: int = 0):
+        self._check(self._lib.hr_search_sparse_dev(self._h, _vp(d_indptr), _vp(d_idx), _vp(d_val), B, nnz_total,
+                                                   max_q_nnz, k, _vp(d_rowmask) if d_rowmask else None, _vp(d_ids),
+                                                   _vp(d_scores), _vp(d_flags) if d_flags else None,
+                                                   _vp(stream) if stream else None))
+
+    # -- measurement
+    def set_profiling(self, level: int):
+        self._check(self._lib.hr_set_profiling(self._h, level))
+
+    def kernel_ms(self):
+        """{phase: (mean ms per launch, launches)} since the previous call."""
+        buf = np.zeros(2 * HR_N_PHASES, dtype=np.float32)
+        self._check(self._lib.hr_last_kernel_ms(self._h, _vp(buf), buf.shape[0]))
+        return {PHASE_NAMES[p]: (float(buf[p]), int(buf[HR_N_PHASES + p])) for p in range(HR_N_PHASES)}
+
+
+def fuse_rrf_dev(d_a: int, ka: int, d_b: int, kb: int, d_c: int, kc: int, B: int, wa: float, wb: float, wc: float,
+                 rrf_k: int, top_k: int, d_out_ids: int, d_out_scores: int, d_out_methods: int, d_n_out: int,
+                 stream: int = 0):
+    L = load_library()
+    rc = L.hr_fuse_rrf_dev(_vp(d_a) if ka else None, ka, _vp(d_b) if kb else None, kb, _vp(d_c) if kc else None, kc,
+                           B, wa, wb, wc, rrf_k, top_k, _vp(d_out_ids), _vp(d_out_scores), _vp(d_out_methods),
+                           _vp(d_n_out), _vp(stream) if stream else None)
+    if rc != 0:
+        msg = (L.hr_last_error(None) or b"").decode()
+        if rc == 1:
+            raise ValueError(msg)
+        raise HbmRagError(rc, msg)
+
+
+def merge_topk_dev(d_scores: int, d_ids: int, n_lists: int, B: int, k_in: int, k_out: int, d_out_ids: int,
+                   d_out_scores: int, stream: int = 0):
+    L = load_library()
+    rc = L.hr_merge_topk_dev(_vp(d_scores), _vp(d_ids), n_lists, B, k_in, k_out, _vp(d_out_ids), _vp(d_out_scores),
+                             _vp(stream) if stream else None)
+    if rc != 0:
+        msg = (L.hr_last_error(None) or b"").decode()
+        if rc == 1:
+            raise ValueError(msg)
+        raise HbmRagError(rc, msg)

@@ -1,0 +1,56 @@
+// Shared device helpers for libhbmrag (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hbmrag.h"
+
+namespace hbmrag {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int chunk_t __attribute__((ext_vector_type(4)));  // one 16-byte chunk
+
+constexpr int kWave = 64;
+constexpr int kRowsPerBlock = 16;   // rows of one MFMA A-tile ("row block")
+constexpr int kRowBlocksPerGroup = 4;  // row blocks whose max is kept as one candidate group
+constexpr int kGroupRows = kRowsPerBlock * kRowBlocksPerGroup;  // 64 rows: one refine wave
+constexpr int kChunkBytes = 16;     // bytes one lane contributes to a tile
+constexpr int kTileChunks = 64;     // chunks (lanes) per 1 KiB tile
+
+// Order-preserving map float -> uint32 (larger float <=> larger key).
+__host__ __device__ inline uint32_t ord_f32(float f) {
+    union { float f; uint32_t u; } c; c.f = f;
+    return (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+}
+__host__ __device__ inline float unord_f32(uint32_t k) {
+    union { float f; uint32_t u; } c;
+    c.u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return c.f;
+}
+// Unique 64-bit ranking key: (score desc, row asc)  <=>  key desc.
+__host__ __device__ inline uint64_t rank_key(float score, uint32_t row) {
+    return ((uint64_t)ord_f32(score) << 32) | (uint64_t)(0xFFFFFFFFu - row);
+}
+__host__ __device__ inline float key_score(uint64_t key) { return unord_f32((uint32_t)(key >> 32)); }
+__host__ __device__ inline uint32_t key_row(uint64_t key) { return 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu); }
+
+// Tiled shard layout.  A row block holds 16 rows; along k it is cut into
+// tiles of 4 chunks (16 B each: 8 halfs or 4 floats).  Tile (rb, kt) is 1 KiB,
+// lane l of a wave owns chunk l: row rb*16 + (l & 15), k-chunk kt*4 + (l >> 4).
+// That is exactly the A-operand register image of v_mfma_f32_16x16x32_f16
+// (and, element j at a time, of v_mfma_f32_16x16x4_f32), so the scan streams
+// the shard with one fully coalesced 16 B/lane load per MFMA step.
+__host__ __device__ inline int64_t chunk_index(int64_t row, int kchunk, int KT) {
+    int64_t rb = row >> 4;
+    int rr = (int)(row & 15);
+    int kt = kchunk >> 2, c = kchunk & 3;
+    return (rb * KT + kt) * kTileChunks + rr + 16 * c;
+}
+
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+}  // namespace hbmrag

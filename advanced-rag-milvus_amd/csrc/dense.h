@@ -1,0 +1,275 @@
+// Dense shard kernels: ingest re-tiling, row norms, query prep, the MFMA scan
+// that streams the shard once per query batch, and the canonical fp64 refine.
+//
+// Replaces the server-side HNSW/COSINE search behind Collection.search
+// (reference src/advanced_rag/indexing.py:503-525) with an exact FLAT scan.
+#pragma once
+#include "common.h"
+
+namespace hbmrag {
+
+// ---------------------------------------------------------------------------
+// ingest: row-major rows -> tiled shard layout (see chunk_index)
+// SRC = float (convert to the store type) or the store type itself.
+template <typename STORE, typename SRC>
+__global__ void tile_rows_kernel(const SRC* __restrict__ src, int64_t n, int dim, int KT,
+                                 int64_t row0, chunk_t* __restrict__ tiles) {
+    constexpr int EPC = kChunkBytes / (int)sizeof(STORE);
+    const int kchunks = KT * 4;
+    int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= n * kchunks) return;
+    int64_t i = tid / kchunks;
+    int kc = (int)(tid - i * kchunks);
+    union { chunk_t v; STORE e[EPC]; } out;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+        int k = kc * EPC + j;
+        out.e[j] = (k < dim) ? (STORE)src[i * dim + k] : (STORE)0;
+    }
+    tiles[chunk_index(row0 + i, kc, KT)] = out.v;
+}
+
+// One thread per row: sum of squares in fp64, k-ordered (the canonical norm the
+// oracle restates), and the fp32 scan scale (1/||x|| for COSINE, 1 for IP).
+template <typename STORE>
+__global__ void row_norms_kernel(const chunk_t* __restrict__ tiles, int KT, int64_t row0, int64_t n,
+                                 int cosine, double* __restrict__ norm2, float* __restrict__ scale,
+                                 unsigned int* __restrict__ max_norm_bits) {
+    constexpr int EPC = kChunkBytes / (int)sizeof(STORE);
+    int64_t r = row0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= row0 + n) return;
+    double s = 0.0;
+    for (int kc = 0; kc < KT * 4; ++kc) {
+        union { chunk_t v; STORE e[EPC]; } c;
+        c.v = tiles[chunk_index(r, kc, KT)];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            double x = (double)c.e[j];
+            s = __dadd_rn(s, __dmul_rn(x, x));
+        }
+    }
+    norm2[r] = s;
+    float nrm = (float)sqrt(s);
+    scale[r] = cosine ? (s > 0.0 ? (float)(1.0 / sqrt(s)) : 0.0f) : 1.0f;
+    atomicMax(max_norm_bits, __float_as_uint(nrm));  // non-negative floats order as uints
+}
+
+// ---------------------------------------------------------------------------
+// query prep: one block per query slot.  Writes the unit-normalised query in
+// the B-operand fragment layout of the scan (fp16 or fp32 to match the shard)
+// and the canonical fp64 |q|^2.  Slots >= B are zero-filled padding.
+template <typename STORE>
+__global__ void prep_queries_kernel(const float* __restrict__ q, int B, int dim, int KT,
+                                    chunk_t* __restrict__ qfrag, double* __restrict__ qn2) {
+    constexpr int EPC = kChunkBytes / (int)sizeof(STORE);
+    const int slot = blockIdx.x;
+    const int g = slot >> 4, col = slot & 15;
+    __shared__ float s_inv;
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        if (slot < B) {
+            const float* qq = q + (int64_t)slot * dim;
+            for (int k = 0; k < dim; ++k) {
+                double x = (double)qq[k];
+                s = __dadd_rn(s, __dmul_rn(x, x));
+            }
+            qn2[slot] = s;
+        }
+        s_inv = (s > 0.0) ? (float)(1.0 / sqrt(s)) : 0.0f;
+    }
+    __syncthreads();
+    const float inv = s_inv;
+    for (int kc = threadIdx.x; kc < KT * 4; kc += blockDim.x) {
+        union { chunk_t v; STORE e[EPC]; } out;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            int k = kc * EPC + j;
+            float x = (slot < B && k < dim) ? q[(int64_t)slot * dim + k] * inv : 0.0f;
+            out.e[j] = (STORE)x;
+        }
+        int kt = kc >> 2, c = kc & 3;
+        qfrag[((int64_t)g * KT + kt) * kTileChunks + col + 16 * c] = out.v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The scan.  A wave owns candidate groups (64 consecutive rows = 4 row blocks)
+// in a grid-stride loop and streams their tiles straight from HBM into VGPRs
+// (no LDS round trip: each byte of the shard is used by exactly one wave).
+// The query batch (16*G queries) sits in LDS in fragment order and is re-read
+// per k-step with conflict-free ds_read_b128.  Per MFMA result the lane holds
+// 4 rows x 1 query; the epilogue keeps only the maximum over the group, so the
+// kernel's output is one float per (query, 64 rows): N/64 * B * 4 bytes.
+//
+// HBM traffic per launch (algorithmic): n_rows * Dpad * sizeof(STORE) + 4 * n_rows.
+template <typename STORE>
+struct Mfma;
+template <>
+struct Mfma<_Float16> {
+    __device__ static inline void run(const chunk_t& a, const chunk_t& b, f32x4_t& c) {
+        union { chunk_t v; half8_t h; } ua, ub;
+        ua.v = a; ub.v = b;
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.h, ub.h, c, 0, 0, 0);
+    }
+};
+template <>
+struct Mfma<float> {
+    // One 16 B chunk = 4 k-values; element j of every lane feeds MFMA step j.
+    // Any k order is fine as long as A and B agree, which the shared chunk
+    // layout guarantees.
+    __device__ static inline void run(const chunk_t& a, const chunk_t& b, f32x4_t& c) {
+        union { chunk_t v; float f[4]; } ua, ub;
+        ua.v = a; ub.v = b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(ua.f[j], ub.f[j], c, 0, 0, 0);
+    }
+};
+
+// PF = depth of the per-wave register prefetch ring (k-steps in flight); KT is
+// padded to a multiple of PF at hr_create so ring slots stay compile-time.
+template <typename STORE, int G, int RS, int PF>
+__global__ __launch_bounds__(512) void dense_scan_kernel(
+    const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
+    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int KT, int64_t n_rows,
+    int64_t n_groups) {
+    extern __shared__ chunk_t lds_q[];  // [G][KT][64] chunks
+    constexpr int kPairs = kRowBlocksPerGroup / RS;
+    const int nq_chunks = G * KT * kTileChunks;
+    for (int i = threadIdx.x; i < nq_chunks; i += blockDim.x) lds_q[i] = qfrag[i];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int waves_per_block = blockDim.x >> 6;
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * waves_per_block + (threadIdx.x >> 6)));
+    const int64_t total_waves = (int64_t)gridDim.x * waves_per_block;
+    const int quad = lane >> 4;
+    const float NEG_INF = -__builtin_inff();
+
+    // Prefetch cursor: walks (group, pair, kt) exactly PF steps ahead of the
+    // consumer, across pair and group boundaries, so the wave's HBM stream
+    // never drains.  All of it is wave-uniform (scalar) state.
+    int64_t pf_group = wave;
+    int pf_pair = 0, pf_kt = 0;
+    chunk_t ring[PF][RS];
+    auto prefetch = [&](int slot) {
+        // Unconditional load (no control flow around VMEM, so the compiler keeps
+        // counted vmcnt waits): past the wave's last group re-read its first one.
+        const int64_t grp = pf_group < n_groups ? pf_group : wave;
+        const int64_t rb = grp * kRowBlocksPerGroup + pf_pair * RS;
+#pragma unroll
+        for (int s = 0; s < RS; ++s)
+            ring[slot][s] = __builtin_nontemporal_load(tiles + ((rb + s) * KT + pf_kt) * kTileChunks + lane);
+        const bool wrap_kt = (pf_kt + 1 == KT);
+        pf_kt = wrap_kt ? 0 : pf_kt + 1;
+        const bool wrap_pair = wrap_kt && (pf_pair + 1 == kPairs);
+        pf_pair = wrap_kt ? (wrap_pair ? 0 : pf_pair + 1) : pf_pair;
+        pf_group = wrap_pair ? pf_group + total_waves : pf_group;
+    };
+#pragma unroll
+    for (int j = 0; j < PF; ++j) prefetch(j);
+
+    for (int64_t group = wave; group < n_groups; group += total_waves) {
+        float m[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) m[g] = NEG_INF;
+        const bool tail = (group + 1) * kGroupRows > n_rows || rowmask != nullptr;
+
+#pragma unroll 1
+        for (int pair = 0; pair < kPairs; ++pair) {
+            f32x4_t acc[RS][G];
+#pragma unroll
+            for (int s = 0; s < RS; ++s)
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[s][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+            for (int kt0 = 0; kt0 < KT; kt0 += PF) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const chunk_t b = lds_q[(g * KT + kt0 + j) * kTileChunks + lane];
+#pragma unroll
+                        for (int s = 0; s < RS; ++s) Mfma<STORE>::run(ring[j][s], b, acc[s][g]);
+                    }
+                    prefetch(j);  // refill the slot just consumed: PF-1 steps of lookahead
+                }
+            }
+            // epilogue: lane holds rows row0..row0+3 of row block s for query 16g+(lane&15)
+#pragma unroll
+            for (int s = 0; s < RS; ++s) {
+                const int64_t row0 = (group * kRowBlocksPerGroup + pair * RS + s) * kRowsPerBlock + quad * 4;
+                const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(scale + row0);
+                float ok[4] = {1.f, 1.f, 1.f, 1.f};
+                if (tail) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int64_t row = row0 + r;
+                        bool v = row < n_rows;
+                        if (v && rowmask) v = (rowmask[row >> 3] >> (row & 7)) & 1;
+                        ok[r] = v ? 1.f : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[s][g][r] * sc[r];
+                        v = (ok[r] != 0.f) ? v : NEG_INF;
+                        m[g] = fmaxf(m[g], v);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float v = m[g];
+            v = fmaxf(v, __shfl_xor(v, 16));
+            v = fmaxf(v, __shfl_xor(v, 32));
+            if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * n_groups + group] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Canonical refine: one wave per (query, candidate group); lane = row.
+// score = (float) S with S the k-ordered fp64 sum of exact products.  The same
+// arithmetic is restated in oracle/oracle.c:dense_score().
+template <typename STORE>
+__global__ __launch_bounds__(64) void refine_dense_kernel(
+    const chunk_t* __restrict__ tiles, int KT, int dim, const float* __restrict__ q,
+    const double* __restrict__ qn2, const double* __restrict__ norm2,
+    const uint8_t* __restrict__ rowmask, const int32_t* __restrict__ cand, int C, int64_t n_rows,
+    int cosine, float* __restrict__ out_score, int32_t* __restrict__ out_row) {
+    constexpr int EPC = kChunkBytes / (int)sizeof(STORE);
+    const int qi = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
+    const int32_t group = cand[(int64_t)qi * C + ci];
+    const int64_t o = ((int64_t)qi * C + ci) * kGroupRows + lane;
+    const int64_t row = (int64_t)group * kGroupRows + lane;
+    bool valid = group >= 0 && row < n_rows;
+    if (valid && rowmask) valid = (rowmask[row >> 3] >> (row & 7)) & 1;
+    if (!valid) {  // whole-wave exit is fine: no cross-lane ops below
+        out_score[o] = -__builtin_inff();
+        out_row[o] = -1;
+        return;
+    }
+    const float* qq = q + (int64_t)qi * dim;
+    double s = 0.0;
+    for (int kc = 0; kc < KT * 4; ++kc) {
+        union { chunk_t v; STORE e[EPC]; } c;
+        c.v = tiles[chunk_index(row, kc, KT)];
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            int k = kc * EPC + j;
+            if (k < dim) s = __dadd_rn(s, __dmul_rn((double)c.e[j], (double)qq[k]));
+        }
+    }
+    if (cosine) {
+        double d = norm2[row] * qn2[qi];
+        s = (d > 0.0) ? s / sqrt(d) : 0.0;
+    }
+    out_score[o] = (float)s;
+    out_row[o] = (int32_t)row;
+}
+
+}  // namespace hbmrag

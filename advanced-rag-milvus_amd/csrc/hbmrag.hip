@@ -1,0 +1,1032 @@
+// libhbmrag.so — host side of the C ABI declared in include/hbmrag.h.
+// Owns the in-HBM shard store (dense tiles + sparse postings) of ONE GPU and
+// launches the gfx950 kernels in dense.h / select.h / sparse.h / fuse.h.
+// There is deliberately no CPU fallback in this file: without a HIP device
+// hr_create fails and every caller sees the error.
+#include "../../include/hbmrag.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <shared_mutex>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "common.h"
+#include "dense.h"
+#include "fuse.h"
+#include "select.h"
+#include "sparse.h"
+
+using namespace hbmrag;
+
+namespace {
+
+thread_local std::string g_last_error;  // for calls without a handle
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum Phase { PH_PREP = 0, PH_SCAN, PH_GSEL, PH_REFINE, PH_TOPK, PH_SSCAN, PH_SGSEL, PH_SREFINE, PH_STOPK, PH_COUNT };
+
+struct Workspace {
+    hipStream_t stream = nullptr;  // own stream (host-form calls)
+    DevBuf qfrag, qn2, gmax, cand, acut, cscore, crow, flags;
+    DevBuf d_q, d_ids, d_scores, d_mask;          // host-form staging
+    DevBuf d_qptr, d_qidx, d_qval;                // sparse query staging
+    DevBuf f_ids, f_out_ids, f_out_scores, f_out_meth, f_n;  // hr_fuse_rrf staging
+    void release() {
+        for (DevBuf* b : {&qfrag, &qn2, &gmax, &cand, &acut, &cscore, &crow, &flags, &d_q, &d_ids, &d_scores,
+                          &d_mask, &d_qptr, &d_qidx, &d_qval, &f_ids, &f_out_ids, &f_out_scores, &f_out_meth, &f_n})
+            b->release();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
+struct EventSpan {
+    int phase;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct hr_index {
+    int device = 0;
+    int64_t dim = 0, sparse_dim = 0;
+    int dtype = HR_F16, metric = HR_METRIC_COSINE;
+    int KT = 0;  // 1 KiB tiles per row block along k
+    int64_t row_offset = 0;
+
+    // dense shard
+    DevBuf tiles, scale, norm2, max_norm;
+    int64_t cap_rows = 0, n_rows = 0, n_normed = 0;
+    float max_row_norm = 0.f;
+    DevBuf stage;  // ingest staging
+    hipStream_t ingest_stream = nullptr;
+
+    // sparse shard: host CSR staging + device copies
+    std::vector<int64_t> h_indptr{0};
+    std::vector<int32_t> h_idx;
+    std::vector<float> h_val;
+    int64_t n_sparse = 0, n_sparse_built = -1;
+    DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post_doc, post_val;
+    int64_t n_ranges = 0;
+
+    bool finalized = false;
+    int profiling = 0;
+    int cu_count = 256;
+
+    mutable std::shared_mutex rw;  // searches shared, add/finalize exclusive
+    std::mutex pool_mu;
+    std::vector<Workspace*> free_ws;
+    std::map<void*, Workspace*> stream_ws;
+    std::mutex prof_mu;
+    std::vector<EventSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    mutable std::mutex err_mu;
+    mutable std::string err;
+};
+
+namespace {
+
+int fail(const hr_index* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) {
+        std::lock_guard<std::mutex> g(h->err_mu);
+        h->err = buf;
+    }
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) return fail(h, HR_EHIP, "%s: %s", #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+#define HR_TRY(expr)               \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != HR_OK) return rc__; \
+    } while (0)
+
+inline size_t elem_size(int dtype) { return dtype == HR_F16 ? 2 : 4; }
+inline int elems_per_chunk(int dtype) { return dtype == HR_F16 ? 8 : 4; }
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline size_t tile_bytes_for_rows(const hr_index* h, int64_t rows) {
+    return (size_t)(rows / kRowsPerBlock) * h->KT * 1024;
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        (void)hipGetDevice(&prev);
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+Workspace* take_ws(hr_index* h) {
+    std::lock_guard<std::mutex> g(h->pool_mu);
+    if (!h->free_ws.empty()) {
+        Workspace* w = h->free_ws.back();
+        h->free_ws.pop_back();
+        return w;
+    }
+    Workspace* w = new (std::nothrow) Workspace();
+    if (!w) return nullptr;
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete w;
+        return nullptr;
+    }
+    return w;
+}
+void give_ws(hr_index* h, Workspace* w) {
+    std::lock_guard<std::mutex> g(h->pool_mu);
+    h->free_ws.push_back(w);
+}
+Workspace* ws_for_stream(hr_index* h, void* stream) {
+    std::lock_guard<std::mutex> g(h->pool_mu);
+    auto it = h->stream_ws.find(stream);
+    if (it != h->stream_ws.end()) return it->second;
+    Workspace* w = new (std::nothrow) Workspace();
+    if (w) h->stream_ws[stream] = w;
+    return w;
+}
+
+// ---- profiling spans -------------------------------------------------------
+struct Span {
+    hr_index* h;
+    hipStream_t s;
+    int phase;
+    hipEvent_t a = nullptr, b = nullptr;
+    Span(hr_index* h_, hipStream_t s_, int phase_) : h(h_), s(s_), phase(phase_) {
+        const bool on = h->profiling >= 2 || (h->profiling == 1 && (phase == PH_SCAN || phase == PH_SSCAN));
+        if (!on) return;
+        std::lock_guard<std::mutex> g(h->prof_mu);
+        auto get = [&]() -> hipEvent_t {
+            hipEvent_t e = nullptr;
+            if (!h->event_pool.empty()) {
+                e = h->event_pool.back();
+                h->event_pool.pop_back();
+            } else if (hipEventCreate(&e) != hipSuccess) {
+                e = nullptr;
+            }
+            return e;
+        };
+        a = get();
+        b = get();
+        if (a && b) (void)hipEventRecord(a, s);
+    }
+    ~Span() {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> g(h->prof_mu);
+        h->spans.push_back({phase, a, b});
+    }
+};
+
+// ---- dense launch helpers ----------------------------------------------------
+template <typename STORE, int G>
+hipError_t launch_scan(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                       int nq, int64_t n_groups) {
+    constexpr int RS = 2, PF = 4;
+    auto kern = dense_scan_kernel<STORE, G, RS, PF>;
+    const size_t lds = (size_t)G * h->KT * 1024;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    // One 1024-thread block per CU when the query tile is large, several
+    // 256-thread blocks per CU otherwise; waves take groups in a grid-stride loop.
+    int threads, per_cu;
+    if (lds > 40 * 1024) {
+        threads = 512;
+        per_cu = 1;
+    } else {
+        threads = 256;
+        per_cu = (int)std::min<size_t>(8, (150 * 1024) / std::max<size_t>(lds, 1));
+    }
+    const int64_t waves_per_block = threads / 64;
+    int64_t blocks = std::min<int64_t>((n_groups + waves_per_block - 1) / waves_per_block,
+                                       (int64_t)h->cu_count * per_cu);
+    blocks = std::max<int64_t>(blocks, 1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, s, h->tiles.as<chunk_t>(), qfrag,
+                       h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_groups);
+    return hipGetLastError();
+}
+
+template <typename STORE>
+hipError_t launch_scan_g(const hr_index* h, hipStream_t s, int G, const chunk_t* qfrag, const uint8_t* mask,
+                         float* gmax, int nq, int64_t n_groups) {
+    switch (G) {
+        case 1: return launch_scan<STORE, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
+        case 2: return launch_scan<STORE, 2>(h, s, qfrag, mask, gmax, nq, n_groups);
+        case 3: return launch_scan<STORE, 3>(h, s, qfrag, mask, gmax, nq, n_groups);
+        default: return launch_scan<STORE, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
+    }
+}
+
+int max_groups_for_dim(const hr_index* h) {
+    // query tile must fit LDS: G * KT KiB <= 144 KiB
+    int g = 156 / std::max(h->KT, 1);
+    return std::max(1, std::min(4, g));
+}
+
+int candidate_groups_for_k(int k) {
+    int c = k + std::max(16, k / 2);
+    return (int)round_up(c, 16);
+}
+
+void dense_eps(const hr_index* h, float* eps_abs, int* norm_mode) {
+    const double Dp = (double)h->KT * 4 * elems_per_chunk(h->dtype);
+    double unit = 2.0 * Dp * std::ldexp(1.0, -24) + 1e-6;        // fp32 accumulation + scale rounding
+    unit += (h->dtype == HR_F16) ? std::ldexp(1.0, -11) * 1.01  // query rounded to fp16
+                                 : std::ldexp(1.0, -22);        // query normalised in fp32
+    if (h->metric == HR_METRIC_COSINE) {
+        *eps_abs = (float)unit;
+        *norm_mode = 0;
+    } else {
+        *eps_abs = (float)(unit * (double)h->max_row_norm * 1.0001);
+        *norm_mode = 1;
+    }
+}
+
+// Enqueue a complete dense search on stream s.  All pointers are device pointers.
+int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float* d_q, int B, int k,
+                         const uint8_t* d_mask, int64_t* d_ids, float* d_scores, int32_t* d_flags, int C) {
+    const int64_t n_groups = (h->n_rows + kGroupRows - 1) / kGroupRows;
+    const int Gmax = max_groups_for_dim(h);
+    const int chunk_q = 16 * Gmax;
+    const size_t qfrag_bytes = (size_t)Gmax * h->KT * 1024;
+    HIP_TRY(h, ws->qfrag.ensure(qfrag_bytes));
+    HIP_TRY(h, ws->qn2.ensure((size_t)B * sizeof(double)));
+    HIP_TRY(h, ws->gmax.ensure((size_t)B * n_groups * sizeof(float)));
+    HIP_TRY(h, ws->cand.ensure((size_t)B * C * sizeof(int32_t)));
+    HIP_TRY(h, ws->acut.ensure((size_t)B * sizeof(float)));
+    HIP_TRY(h, ws->cscore.ensure((size_t)B * C * kGroupRows * sizeof(float)));
+    HIP_TRY(h, ws->crow.ensure((size_t)B * C * kGroupRows * sizeof(int32_t)));
+
+    for (int c0 = 0; c0 < B; c0 += chunk_q) {
+        const int nq = std::min(chunk_q, B - c0);
+        const int G = (nq + 15) / 16;
+        {
+            Span sp(h, s, PH_PREP);
+            if (h->dtype == HR_F16)
+                hipLaunchKernelGGL((prep_queries_kernel<_Float16>), dim3(16 * G), dim3(256), 0, s,
+                                   d_q + (int64_t)c0 * h->dim, nq, (int)h->dim, h->KT, ws->qfrag.as<chunk_t>(),
+                                   ws->qn2.as<double>() + c0);
+            else
+                hipLaunchKernelGGL((prep_queries_kernel<float>), dim3(16 * G), dim3(256), 0, s,
+                                   d_q + (int64_t)c0 * h->dim, nq, (int)h->dim, h->KT, ws->qfrag.as<chunk_t>(),
+                                   ws->qn2.as<double>() + c0);
+            HIP_TRY(h, hipGetLastError());
+        }
+        {
+            Span sp(h, s, PH_SCAN);
+            float* gm = ws->gmax.as<float>() + (int64_t)c0 * n_groups;
+            hipError_t e = (h->dtype == HR_F16)
+                               ? launch_scan_g<_Float16>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_groups)
+                               : launch_scan_g<float>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_groups);
+            HIP_TRY(h, e);
+        }
+    }
+    {
+        Span sp(h, s, PH_GSEL);
+        hipLaunchKernelGGL(select_groups_kernel, dim3(B), dim3(1024), 0, s, ws->gmax.as<float>(), n_groups, C,
+                           ws->cand.as<int32_t>(), ws->acut.as<float>());
+        HIP_TRY(h, hipGetLastError());
+    }
+    {
+        Span sp(h, s, PH_REFINE);
+        const int cosine = h->metric == HR_METRIC_COSINE;
+        if (h->dtype == HR_F16)
+            hipLaunchKernelGGL((refine_dense_kernel<_Float16>), dim3(C, B), dim3(64), 0, s, h->tiles.as<chunk_t>(),
+                               h->KT, (int)h->dim, d_q, ws->qn2.as<double>(), h->norm2.as<double>(), d_mask,
+                               ws->cand.as<int32_t>(), C, h->n_rows, cosine, ws->cscore.as<float>(),
+                               ws->crow.as<int32_t>());
+        else
+            hipLaunchKernelGGL((refine_dense_kernel<float>), dim3(C, B), dim3(64), 0, s, h->tiles.as<chunk_t>(),
+                               h->KT, (int)h->dim, d_q, ws->qn2.as<double>(), h->norm2.as<double>(), d_mask,
+                               ws->cand.as<int32_t>(), C, h->n_rows, cosine, ws->cscore.as<float>(),
+                               ws->crow.as<int32_t>());
+        HIP_TRY(h, hipGetLastError());
+    }
+    {
+        Span sp(h, s, PH_TOPK);
+        float eps_abs;
+        int norm_mode;
+        dense_eps(h, &eps_abs, &norm_mode);
+        hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), 0, s, ws->cscore.as<float>(),
+                           ws->crow.as<int32_t>(), C * kGroupRows, k, h->row_offset, ws->acut.as<float>(),
+                           -INFINITY, eps_abs, 0.0f, norm_mode, ws->qn2.as<double>(), d_ids, d_scores, d_flags);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return HR_OK;
+}
+
+int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64_t* d_qptr, const int32_t* d_qidx,
+                          const float* d_qval, int B, int max_q_nnz, int k, const uint8_t* d_mask, int64_t* d_ids,
+                          float* d_scores, int32_t* d_flags, int C) {
+    const int64_t n_groups = (h->n_sparse + kGroupRows - 1) / kGroupRows;
+    HIP_TRY(h, ws->gmax.ensure((size_t)B * n_groups * sizeof(float)));
+    HIP_TRY(h, ws->cand.ensure((size_t)B * C * sizeof(int32_t)));
+    HIP_TRY(h, ws->acut.ensure((size_t)B * sizeof(float)));
+    HIP_TRY(h, ws->cscore.ensure((size_t)B * C * kGroupRows * sizeof(float)));
+    HIP_TRY(h, ws->crow.ensure((size_t)B * C * kGroupRows * sizeof(int32_t)));
+    const int64_t V1 = h->sparse_dim + 1;
+    for (int q0 = 0; q0 < B; q0 += 32768) {  // gridDim.y limit
+        const int nq = std::min(32768, B - q0);
+        Span sp(h, s, PH_SSCAN);
+        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(256), 0, s,
+                           h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(),
+                           h->post_doc.as<uint16_t>(), h->post_val.as<float>(), d_qptr + q0, d_qidx, d_qval, d_mask,
+                           h->n_sparse, n_groups, ws->gmax.as<float>() + (int64_t)q0 * n_groups);
+        HIP_TRY(h, hipGetLastError());
+    }
+    {
+        Span sp(h, s, PH_SGSEL);
+        hipLaunchKernelGGL(select_groups_kernel, dim3(B), dim3(1024), 0, s, ws->gmax.as<float>(), n_groups, C,
+                           ws->cand.as<int32_t>(), ws->acut.as<float>());
+        HIP_TRY(h, hipGetLastError());
+    }
+    {
+        Span sp(h, s, PH_SREFINE);
+        hipLaunchKernelGGL(refine_sparse_kernel, dim3(C, B), dim3(64), 0, s, h->s_indptr.as<int64_t>(),
+                           h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
+                           ws->cand.as<int32_t>(), C, h->n_sparse, ws->cscore.as<float>(), ws->crow.as<int32_t>());
+        HIP_TRY(h, hipGetLastError());
+    }
+    {
+        Span sp(h, s, PH_STOPK);
+        // fp32 products and fp32 LDS atomic adds in arbitrary order over <= max_q_nnz
+        // non-negative terms: relative error of the scan's sums.
+        const float eps_rel = (float)(2.0 * (max_q_nnz + 2) * std::ldexp(1.0, -24));
+        hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), 0, s, ws->cscore.as<float>(),
+                           ws->crow.as<int32_t>(), C * kGroupRows, k, h->row_offset, ws->acut.as<float>(), 0.0f, 0.0f,
+                           eps_rel, 0, (const double*)nullptr, d_ids, d_scores, d_flags);
+        HIP_TRY(h, hipGetLastError());
+    }
+    return HR_OK;
+}
+
+int check_search_args(hr_index* h, int B, int k, bool dense) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (B <= 0) return fail(h, HR_EINVAL, "batch size must be positive (got %d)", B);
+    if (k <= 0) return fail(h, HR_EINVAL, "k must be positive (got %d)", k);
+    if (k > HR_MAX_TOPK) return fail(h, HR_ELIMIT, "k=%d exceeds HR_MAX_TOPK=%d", k, HR_MAX_TOPK);
+    if (!h->finalized) return fail(h, HR_ESTATE, "search before hr_finalize");
+    if (dense && h->dim == 0) return fail(h, HR_ESTATE, "handle has no dense collection");
+    if (!dense && h->sparse_dim == 0) return fail(h, HR_ESTATE, "handle has no sparse collection");
+    return HR_OK;
+}
+
+// Results for an empty collection: all padding, proven exact.
+int fill_empty(hr_index* h, hipStream_t s, int B, int k, int64_t* d_ids, float* d_scores, int32_t* d_flags) {
+    HIP_TRY(h, hipMemsetAsync(d_ids, 0xFF, (size_t)B * k * sizeof(int64_t), s));
+    HIP_TRY(h, hipMemsetAsync(d_scores, 0, (size_t)B * k * sizeof(float), s));
+    if (d_flags) {
+        std::vector<int32_t> ones(B, 1);
+        HIP_TRY(h, hipMemcpyAsync(d_flags, ones.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
+    return HR_OK;
+}
+
+int grow_dense(hr_index* h, int64_t need_rows) {
+    if (need_rows <= h->cap_rows) return HR_OK;
+    int64_t new_cap = std::max<int64_t>(round_up(need_rows, kGroupRows),
+                                        round_up(h->cap_rows + h->cap_rows / 2, kGroupRows));
+    new_cap = std::max<int64_t>(new_cap, 1024);
+    DevBuf nt, ns, nn;
+    const size_t tb = tile_bytes_for_rows(h, new_cap);
+    if (hipMalloc(&nt.p, tb) != hipSuccess || hipMalloc(&ns.p, (size_t)new_cap * 4) != hipSuccess ||
+        hipMalloc(&nn.p, (size_t)new_cap * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        nt.cap = ns.cap = nn.cap = 1;
+        nt.release(); ns.release(); nn.release();
+        return fail(h, HR_ENOMEM, "cannot allocate dense shard for %lld rows (%zu bytes)", (long long)new_cap, tb);
+    }
+    nt.cap = tb; ns.cap = (size_t)new_cap * 4; nn.cap = (size_t)new_cap * 8;
+    hipStream_t s = h->ingest_stream;
+    HIP_TRY(h, hipMemsetAsync(nt.p, 0, tb, s));
+    HIP_TRY(h, hipMemsetAsync(ns.p, 0, ns.cap, s));
+    HIP_TRY(h, hipMemsetAsync(nn.p, 0, nn.cap, s));
+    if (h->cap_rows > 0) {
+        HIP_TRY(h, hipMemcpyAsync(nt.p, h->tiles.p, tile_bytes_for_rows(h, h->cap_rows), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(ns.p, h->scale.p, (size_t)h->cap_rows * 4, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(nn.p, h->norm2.p, (size_t)h->cap_rows * 8, hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    h->tiles.release(); h->scale.release(); h->norm2.release();
+    h->tiles = nt; h->scale = ns; h->norm2 = nn;
+    h->cap_rows = new_cap;
+    return HR_OK;
+}
+
+template <typename SRC>
+int add_dense_impl(hr_index* h, const SRC* rows, int64_t n, bool src_on_device, hipStream_t user_stream) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (h->dim == 0) return fail(h, HR_ESTATE, "handle has no dense collection");
+    if (n < 0 || (n > 0 && !rows)) return fail(h, HR_EINVAL, "bad rows/n");
+    if (n == 0) return HR_OK;
+    std::unique_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    HR_TRY(grow_dense(h, h->n_rows + n));
+    hipStream_t s = src_on_device && user_stream ? user_stream : h->ingest_stream;
+    const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / (h->dim * (int64_t)sizeof(SRC)));
+    const int kchunks = h->KT * 4;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        const int64_t m = std::min(chunk_rows, n - r0);
+        const SRC* src = rows + r0 * h->dim;
+        if (!src_on_device) {
+            HIP_TRY(h, h->stage.ensure((size_t)m * h->dim * sizeof(SRC)));
+            HIP_TRY(h, hipMemcpyAsync(h->stage.p, src, (size_t)m * h->dim * sizeof(SRC), hipMemcpyHostToDevice, s));
+            src = h->stage.as<SRC>();
+        }
+        const int64_t threads = m * kchunks;
+        const unsigned blocks = (unsigned)((threads + 255) / 256);
+        if (h->dtype == HR_F16) {
+            if constexpr (std::is_same<SRC, float>::value)
+                hipLaunchKernelGGL((tile_rows_kernel<_Float16, float>), dim3(blocks), dim3(256), 0, s, src, m,
+                                   (int)h->dim, h->KT, h->n_rows + r0, h->tiles.as<chunk_t>());
+            else
+                hipLaunchKernelGGL((tile_rows_kernel<_Float16, _Float16>), dim3(blocks), dim3(256), 0, s,
+                                   reinterpret_cast<const _Float16*>(src), m, (int)h->dim, h->KT, h->n_rows + r0,
+                                   h->tiles.as<chunk_t>());
+        } else {
+            hipLaunchKernelGGL((tile_rows_kernel<float, float>), dim3(blocks), dim3(256), 0, s,
+                               reinterpret_cast<const float*>(src), m, (int)h->dim, h->KT, h->n_rows + r0,
+                               h->tiles.as<chunk_t>());
+        }
+        HIP_TRY(h, hipGetLastError());
+        if (!src_on_device) HIP_TRY(h, hipStreamSynchronize(s));  // staging buffer is reused
+    }
+    HIP_TRY(h, hipStreamSynchronize(s));
+    h->n_rows += n;
+    h->finalized = false;
+    return HR_OK;
+}
+
+int build_sparse(hr_index* h) {
+    hipStream_t s = h->ingest_stream;
+    const int64_t n = h->n_sparse;
+    const int64_t nnz = (int64_t)h->h_idx.size();
+    const int64_t V1 = h->sparse_dim + 1;
+    h->n_ranges = (n + kRangeDocs - 1) / kRangeDocs;
+    if (n == 0) {
+        h->n_sparse_built = 0;
+        return HR_OK;
+    }
+    HIP_TRY(h, h->s_indptr.ensure((size_t)(n + 1) * 8));
+    HIP_TRY(h, h->s_idx.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    HIP_TRY(h, h->s_val.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    HIP_TRY(h, hipMemcpyAsync(h->s_indptr.p, h->h_indptr.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (nnz) {
+        HIP_TRY(h, hipMemcpyAsync(h->s_idx.p, h->h_idx.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(h->s_val.p, h->h_val.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, s));
+    }
+    const size_t off_bytes = (size_t)h->n_ranges * V1 * 4;
+    HIP_TRY(h, h->rt_off.ensure(off_bytes));
+    HIP_TRY(h, h->range_base.ensure((size_t)(h->n_ranges + 1) * 8));
+    HIP_TRY(h, h->post_doc.ensure((size_t)std::max<int64_t>(nnz, 1) * 2));
+    HIP_TRY(h, h->post_val.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    HIP_TRY(h, hipMemsetAsync(h->rt_off.p, 0, off_bytes, s));
+    const unsigned doc_blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(sparse_count_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
+                       h->s_idx.as<int32_t>(), n, V1, h->rt_off.as<unsigned int>());
+    HIP_TRY(h, hipGetLastError());
+    DevBuf totals, cursor;
+    HIP_TRY(h, totals.ensure((size_t)h->n_ranges * 8));
+    hipLaunchKernelGGL(sparse_scan_offsets_kernel, dim3((unsigned)h->n_ranges), dim3(1024), 0, s,
+                       h->rt_off.as<unsigned int>(), V1, totals.as<unsigned long long>());
+    HIP_TRY(h, hipGetLastError());
+    std::vector<unsigned long long> ht(h->n_ranges);
+    HIP_TRY(h, hipMemcpyAsync(ht.data(), totals.p, (size_t)h->n_ranges * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::vector<int64_t> base(h->n_ranges + 1, 0);
+    for (int64_t r = 0; r < h->n_ranges; ++r) base[r + 1] = base[r] + (int64_t)ht[r];
+    HIP_TRY(h, hipMemcpyAsync(h->range_base.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, s));
+    hipError_t e = cursor.ensure(off_bytes);
+    if (e != hipSuccess) {
+        totals.release();
+        return fail(h, HR_ENOMEM, "sparse build cursor: %s", hipGetErrorString(e));
+    }
+    HIP_TRY(h, hipMemcpyAsync(cursor.p, h->rt_off.p, off_bytes, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(sparse_fill_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
+                       h->s_idx.as<int32_t>(), h->s_val.as<float>(), n, V1, cursor.as<unsigned int>(),
+                       h->range_base.as<int64_t>(), h->post_doc.as<uint16_t>(), h->post_val.as<float>());
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(s));
+    totals.release();
+    cursor.release();
+    h->n_sparse_built = n;
+    return HR_OK;
+}
+
+}  // namespace
+
+// =============================================================================
+extern "C" {
+
+int hr_version(void) { return 100; }
+
+const char* hr_last_error(const hr_index* h) {
+    if (!h) return g_last_error.c_str();
+    std::lock_guard<std::mutex> g(h->err_mu);
+    g_last_error = h->err;  // hand back a pointer that outlives the lock
+    return g_last_error.c_str();
+}
+
+int hr_create(int device, int64_t dim, int dtype, int metric, int64_t sparse_dim, hr_index** out) {
+    if (!out) return fail(nullptr, HR_EINVAL, "out is null");
+    *out = nullptr;
+    if (dim < 0 || sparse_dim < 0 || (dim == 0 && sparse_dim == 0))
+        return fail(nullptr, HR_EINVAL, "need dim > 0 and/or sparse_dim > 0");
+    if (dim > HR_MAX_DIM) return fail(nullptr, HR_ELIMIT, "dim=%lld exceeds HR_MAX_DIM=%d", (long long)dim, HR_MAX_DIM);
+    if (dtype != HR_F32 && dtype != HR_F16) return fail(nullptr, HR_EINVAL, "unknown dtype %d", dtype);
+    if (metric != HR_METRIC_IP && metric != HR_METRIC_COSINE) return fail(nullptr, HR_EINVAL, "unknown metric %d", metric);
+    if (sparse_dim > (1ll << 24)) return fail(nullptr, HR_ELIMIT, "sparse_dim too large");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(nullptr, HR_EHIP, "no HIP device available (%s); libhbmrag has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= count) return fail(nullptr, HR_EINVAL, "device %d out of range (0..%d)", device, count - 1);
+    hr_index* h = new (std::nothrow) hr_index();
+    if (!h) return fail(nullptr, HR_ENOMEM, "out of host memory");
+    h->device = device;
+    h->dim = dim;
+    h->dtype = dtype;
+    h->metric = metric;
+    h->sparse_dim = sparse_dim;
+    if (dim > 0) {
+        const int tile_elems = 4 * elems_per_chunk(dtype);
+        h->KT = (int)round_up((dim + tile_elems - 1) / tile_elems, 4);  // multiple of the scan's prefetch depth
+    }
+    DeviceGuard dg(device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&h->ingest_stream, hipStreamNonBlocking) != hipSuccess ||
+        h->max_norm.ensure(4) != hipSuccess || hipMemset(h->max_norm.p, 0, 4) != hipSuccess) {
+        int rc = fail(nullptr, HR_EHIP, "device %d initialisation failed: %s", device, hipGetErrorString(hipGetLastError()));
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return HR_OK;
+}
+
+void hr_destroy(hr_index* h) {
+    if (!h) return;
+    {
+        DeviceGuard dg(h->device);
+        (void)hipDeviceSynchronize();
+        for (Workspace* w : h->free_ws) { w->release(); delete w; }
+        for (auto& kv : h->stream_ws) { kv.second->release(); delete kv.second; }
+        for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+        for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
+        for (DevBuf* b : {&h->tiles, &h->scale, &h->norm2, &h->max_norm, &h->stage, &h->s_indptr, &h->s_idx, &h->s_val,
+                          &h->rt_off, &h->range_base, &h->post_doc, &h->post_val})
+            b->release();
+        if (h->ingest_stream) (void)hipStreamDestroy(h->ingest_stream);
+    }
+    delete h;
+}
+
+int hr_set_row_offset(hr_index* h, int64_t first_row) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (first_row < 0) return fail(h, HR_EINVAL, "row offset must be >= 0");
+    h->row_offset = first_row;
+    return HR_OK;
+}
+
+int hr_reserve(hr_index* h, int64_t n_rows) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (h->dim == 0) return fail(h, HR_ESTATE, "handle has no dense collection");
+    if (n_rows < 0 || n_rows > (1ll << 31) - 64) return fail(h, HR_ELIMIT, "row count out of range");
+    std::unique_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    if (n_rows <= h->cap_rows) return HR_OK;
+    // exact-size allocation: temporarily defeat the 1.5x growth policy
+    const int64_t want = round_up(n_rows, kGroupRows);
+    const int64_t saved = h->cap_rows;
+    if (saved == 0) {
+        h->cap_rows = 0;
+        DevBuf nt, ns, nn;
+        const size_t tb = tile_bytes_for_rows(h, std::max<int64_t>(want, kGroupRows));
+        const int64_t rows = std::max<int64_t>(want, kGroupRows);
+        if (hipMalloc(&nt.p, tb) != hipSuccess || hipMalloc(&ns.p, (size_t)rows * 4) != hipSuccess ||
+            hipMalloc(&nn.p, (size_t)rows * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            nt.cap = ns.cap = nn.cap = 1;
+            nt.release(); ns.release(); nn.release();
+            return fail(h, HR_ENOMEM, "cannot reserve %lld rows", (long long)n_rows);
+        }
+        nt.cap = tb; ns.cap = (size_t)rows * 4; nn.cap = (size_t)rows * 8;
+        HIP_TRY(h, hipMemsetAsync(nt.p, 0, tb, h->ingest_stream));
+        HIP_TRY(h, hipMemsetAsync(ns.p, 0, ns.cap, h->ingest_stream));
+        HIP_TRY(h, hipMemsetAsync(nn.p, 0, nn.cap, h->ingest_stream));
+        HIP_TRY(h, hipStreamSynchronize(h->ingest_stream));
+        h->tiles = nt; h->scale = ns; h->norm2 = nn;
+        h->cap_rows = rows;
+        return HR_OK;
+    }
+    return grow_dense(h, want);
+}
+
+int hr_add_dense(hr_index* h, const float* rows, int64_t n) {
+    return add_dense_impl<float>(h, rows, n, false, nullptr);
+}
+
+int hr_add_dense_raw(hr_index* h, const void* rows, int64_t n) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (h->dtype == HR_F16) return add_dense_impl<_Float16>(h, static_cast<const _Float16*>(rows), n, false, nullptr);
+    return add_dense_impl<float>(h, static_cast<const float*>(rows), n, false, nullptr);
+}
+
+int hr_add_dense_raw_dev(hr_index* h, const void* d_rows, int64_t n, void* stream) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (h->dtype == HR_F16)
+        return add_dense_impl<_Float16>(h, static_cast<const _Float16*>(d_rows), n, true, (hipStream_t)stream);
+    return add_dense_impl<float>(h, static_cast<const float*>(d_rows), n, true, (hipStream_t)stream);
+}
+
+int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (h->sparse_dim == 0) return fail(h, HR_ESTATE, "handle has no sparse collection");
+    if (n < 0 || (n > 0 && !indptr)) return fail(h, HR_EINVAL, "bad indptr/n");
+    if (n == 0) return HR_OK;
+    const int64_t nnz = indptr[n] - indptr[0];
+    if (nnz < 0 || (nnz > 0 && (!indices || !values))) return fail(h, HR_EINVAL, "bad indices/values");
+    for (int64_t r = 0; r < n; ++r) {
+        if (indptr[r + 1] < indptr[r]) return fail(h, HR_EINVAL, "indptr not monotone at row %lld", (long long)r);
+        int32_t prev = -1;
+        for (int64_t e = indptr[r]; e < indptr[r + 1]; ++e) {
+            const int32_t t = indices[e];
+            if (t < 0 || t >= h->sparse_dim)
+                return fail(h, HR_EINVAL, "sparse index %d out of range [0,%lld) in row %lld", t, (long long)h->sparse_dim, (long long)r);
+            if (t <= prev) return fail(h, HR_EINVAL, "sparse indices must be strictly ascending (row %lld)", (long long)r);
+            prev = t;
+        }
+    }
+    std::unique_lock<std::shared_mutex> lk(h->rw);
+    if (h->n_sparse + n > (1ll << 31) - 64) return fail(h, HR_ELIMIT, "too many sparse rows");
+    try {
+        const int64_t base = h->h_indptr.back() - indptr[0];
+        h->h_indptr.reserve(h->h_indptr.size() + n);
+        for (int64_t r = 1; r <= n; ++r) h->h_indptr.push_back(indptr[r] + base);
+        h->h_idx.insert(h->h_idx.end(), indices + indptr[0], indices + indptr[n]);
+        h->h_val.insert(h->h_val.end(), values + indptr[0], values + indptr[n]);
+    } catch (const std::bad_alloc&) {
+        return fail(h, HR_ENOMEM, "out of host memory staging sparse rows");
+    }
+    h->n_sparse += n;
+    h->finalized = false;
+    return HR_OK;
+}
+
+int hr_finalize(hr_index* h) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    std::unique_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    hipStream_t s = h->ingest_stream;
+    if (h->dim > 0 && h->n_normed < h->n_rows) {
+        const int64_t n = h->n_rows - h->n_normed;
+        const unsigned blocks = (unsigned)((n + 255) / 256);
+        const int cosine = h->metric == HR_METRIC_COSINE;
+        if (h->dtype == HR_F16)
+            hipLaunchKernelGGL((row_norms_kernel<_Float16>), dim3(blocks), dim3(256), 0, s, h->tiles.as<chunk_t>(),
+                               h->KT, h->n_normed, n, cosine, h->norm2.as<double>(), h->scale.as<float>(),
+                               h->max_norm.as<unsigned int>());
+        else
+            hipLaunchKernelGGL((row_norms_kernel<float>), dim3(blocks), dim3(256), 0, s, h->tiles.as<chunk_t>(), h->KT,
+                               h->n_normed, n, cosine, h->norm2.as<double>(), h->scale.as<float>(),
+                               h->max_norm.as<unsigned int>());
+        HIP_TRY(h, hipGetLastError());
+        unsigned int bits = 0;
+        HIP_TRY(h, hipMemcpyAsync(&bits, h->max_norm.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        std::memcpy(&h->max_row_norm, &bits, 4);
+        h->n_normed = h->n_rows;
+    }
+    if (h->sparse_dim > 0 && h->n_sparse_built != h->n_sparse) HR_TRY(build_sparse(h));
+    h->finalized = true;
+    return HR_OK;
+}
+
+int64_t hr_num_rows(const hr_index* h) { return h ? h->n_rows : 0; }
+int64_t hr_num_sparse_rows(const hr_index* h) { return h ? h->n_sparse : 0; }
+int64_t hr_device_bytes(const hr_index* h) {
+    if (!h) return 0;
+    size_t t = 0;
+    for (const DevBuf* b : {&h->tiles, &h->scale, &h->norm2, &h->s_indptr, &h->s_idx, &h->s_val, &h->rt_off,
+                            &h->range_base, &h->post_doc, &h->post_val})
+        t += b->cap;
+    return (int64_t)t;
+}
+int64_t hr_dense_scan_bytes(const hr_index* h) {
+    if (!h || h->dim == 0) return 0;
+    const int64_t dpad = (int64_t)h->KT * 4 * elems_per_chunk(h->dtype);
+    return h->n_rows * dpad * (int64_t)elem_size(h->dtype) + h->n_rows * 4;
+}
+
+// ---- device-pointer, asynchronous forms -----------------------------------------
+int hr_search_dense_dev(hr_index* h, const float* d_q, int B, int k, const uint8_t* d_rowmask, int64_t* d_ids,
+                        float* d_scores, int32_t* d_flags, void* stream) {
+    HR_TRY(check_search_args(h, B, k, true));
+    if (!d_q || !d_ids || !d_scores) return fail(h, HR_EINVAL, "null buffer");
+    std::shared_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (h->n_rows == 0) return fill_empty(h, s, B, k, d_ids, d_scores, d_flags);
+    Workspace* ws = ws_for_stream(h, stream);
+    if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
+    return dense_search_enqueue(h, ws, s, d_q, B, k, d_rowmask, d_ids, d_scores, d_flags, candidate_groups_for_k(k));
+}
+
+int hr_search_sparse_dev(hr_index* h, const int64_t* d_q_indptr, const int32_t* d_q_idx, const float* d_q_val, int B,
+                         int64_t q_nnz_total, int max_q_nnz, int k, const uint8_t* d_rowmask, int64_t* d_ids,
+                         float* d_scores, int32_t* d_flags, void* stream) {
+    HR_TRY(check_search_args(h, B, k, false));
+    if (!d_q_indptr || !d_ids || !d_scores || (q_nnz_total > 0 && (!d_q_idx || !d_q_val)))
+        return fail(h, HR_EINVAL, "null buffer");
+    if (max_q_nnz < 0 || max_q_nnz > HR_MAX_QUERY_NNZ) return fail(h, HR_ELIMIT, "query nnz exceeds HR_MAX_QUERY_NNZ");
+    std::shared_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (h->n_sparse == 0) return fill_empty(h, s, B, k, d_ids, d_scores, d_flags);
+    Workspace* ws = ws_for_stream(h, stream);
+    if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
+    return sparse_search_enqueue(h, ws, s, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, d_ids, d_scores,
+                                 d_flags, candidate_groups_for_k(k));
+}
+
+int hr_fuse_rrf_dev(const int64_t* d_ids_a, int ka, const int64_t* d_ids_b, int kb, const int64_t* d_ids_c, int kc,
+                    int B, double wa, double wb, double wc, int rrf_k, int top_k, int64_t* d_out_ids,
+                    double* d_out_scores, int32_t* d_out_methods, int32_t* d_n_out, void* stream) {
+    if (B <= 0 || ka < 0 || kb < 0 || kc < 0 || top_k <= 0) return fail(nullptr, HR_EINVAL, "bad fuse sizes");
+    if (ka > HR_MAX_TOPK || kb > HR_MAX_TOPK || kc > HR_MAX_TOPK)
+        return fail(nullptr, HR_ELIMIT, "list longer than HR_MAX_TOPK=%d", HR_MAX_TOPK);
+    if ((ka && !d_ids_a) || (kb && !d_ids_b) || (kc && !d_ids_c) || !d_out_ids || !d_out_scores || !d_out_methods || !d_n_out)
+        return fail(nullptr, HR_EINVAL, "null buffer");
+    hipLaunchKernelGGL(rrf_fuse_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, d_ids_a, ka, d_ids_b, kb, d_ids_c, kc,
+                       wa, wb, wc, rrf_k, top_k, d_out_ids, d_out_scores, d_out_methods, d_n_out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "rrf_fuse_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_merge_topk_dev(const float* d_scores, const int64_t* d_ids, int n_lists, int B, int k_in, int k_out,
+                      int64_t* d_out_ids, float* d_out_scores, void* stream) {
+    if (n_lists <= 0 || B <= 0 || k_in <= 0 || k_out <= 0) return fail(nullptr, HR_EINVAL, "bad merge sizes");
+    if (!d_scores || !d_ids || !d_out_ids || !d_out_scores) return fail(nullptr, HR_EINVAL, "null buffer");
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, d_scores, d_ids, n_lists, B, k_in,
+                       k_out, d_out_ids, d_out_scores);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "merge_topk_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+// ---- host-buffer, synchronous forms -------------------------------------------------
+int hr_search_dense(hr_index* h, const float* q, int B, int k, const uint8_t* rowmask, int64_t* out_ids,
+                    float* out_scores) {
+    HR_TRY(check_search_args(h, B, k, true));
+    if (!q || !out_ids || !out_scores) return fail(h, HR_EINVAL, "null buffer");
+    std::shared_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    if (h->n_rows == 0) {
+        std::fill(out_ids, out_ids + (size_t)B * k, (int64_t)-1);
+        std::fill(out_scores, out_scores + (size_t)B * k, 0.f);
+        return HR_OK;
+    }
+    Workspace* ws = take_ws(h);
+    if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
+    struct Giver { hr_index* h; Workspace* w; ~Giver() { give_ws(h, w); } } giver{h, ws};
+    hipStream_t s = ws->stream;
+    HIP_TRY(h, ws->d_q.ensure((size_t)B * h->dim * 4));
+    HIP_TRY(h, ws->d_ids.ensure((size_t)B * k * 8));
+    HIP_TRY(h, ws->d_scores.ensure((size_t)B * k * 4));
+    HIP_TRY(h, ws->flags.ensure((size_t)B * 4));
+    HIP_TRY(h, hipMemcpyAsync(ws->d_q.p, q, (size_t)B * h->dim * 4, hipMemcpyHostToDevice, s));
+    const uint8_t* d_mask = nullptr;
+    if (rowmask) {
+        const size_t mb = (size_t)(h->n_rows + 7) / 8;
+        HIP_TRY(h, ws->d_mask.ensure(mb));
+        HIP_TRY(h, hipMemcpyAsync(ws->d_mask.p, rowmask, mb, hipMemcpyHostToDevice, s));
+        d_mask = ws->d_mask.as<uint8_t>();
+    }
+    const int64_t n_groups = (h->n_rows + kGroupRows - 1) / kGroupRows;
+    int C = candidate_groups_for_k(k);
+    std::vector<int32_t> flags(B);
+    for (;;) {
+        HR_TRY(dense_search_enqueue(h, ws, s, ws->d_q.as<float>(), B, k, d_mask, ws->d_ids.as<int64_t>(),
+                                    ws->d_scores.as<float>(), ws->flags.as<int32_t>(), C));
+        HIP_TRY(h, hipMemcpyAsync(flags.data(), ws->flags.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        const bool all_exact = std::all_of(flags.begin(), flags.end(), [](int32_t f) { return f != 0; });
+        if (all_exact || C >= n_groups) break;
+        C = (int)std::min<int64_t>((int64_t)C * 4, round_up(n_groups, 16));  // widen the candidate set and redo
+    }
+    HIP_TRY(h, hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HR_OK;
+}
+
+int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val, int B, int k,
+                     float drop_ratio, const uint8_t* rowmask, int64_t* out_ids, float* out_scores) {
+    HR_TRY(check_search_args(h, B, k, false));
+    if (!q_indptr || !out_ids || !out_scores) return fail(h, HR_EINVAL, "null buffer");
+    if (!(drop_ratio >= 0.f && drop_ratio < 1.f)) return fail(h, HR_EINVAL, "drop_ratio must be in [0,1)");
+    // Host prep: drop the floor(drop_ratio*nnz) smallest-|value| entries (ties:
+    // the later entry goes first), then order by index.
+    std::vector<int64_t> ptr(B + 1, 0);
+    std::vector<int32_t> idx;
+    std::vector<float> val;
+    int max_nnz = 0;
+    for (int b = 0; b < B; ++b) {
+        const int64_t e0 = q_indptr[b], e1 = q_indptr[b + 1];
+        if (e1 < e0) return fail(h, HR_EINVAL, "query indptr not monotone");
+        const int nnz = (int)(e1 - e0);
+        if (nnz > 0 && (!q_idx || !q_val)) return fail(h, HR_EINVAL, "null query arrays");
+        std::vector<int> order(nnz);
+        for (int i = 0; i < nnz; ++i) order[i] = i;
+        const int n_drop = (int)std::floor((double)drop_ratio * nnz);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+            const float fa = std::fabs(q_val[e0 + a]), fc = std::fabs(q_val[e0 + c]);
+            if (fa != fc) return fa < fc;
+            return a > c;
+        });
+        std::vector<int> keep(order.begin() + n_drop, order.end());
+        std::sort(keep.begin(), keep.end(), [&](int a, int c) { return q_idx[e0 + a] < q_idx[e0 + c]; });
+        int32_t prev = -1;
+        for (int i : keep) {
+            const int32_t t = q_idx[e0 + i];
+            if (t < 0 || t >= h->sparse_dim) return fail(h, HR_EINVAL, "query index %d out of range", t);
+            if (t == prev) return fail(h, HR_EINVAL, "duplicate query index %d", t);
+            prev = t;
+            idx.push_back(t);
+            val.push_back(q_val[e0 + i]);
+        }
+        ptr[b + 1] = (int64_t)idx.size();
+        max_nnz = std::max(max_nnz, (int)keep.size());
+    }
+    if (max_nnz > HR_MAX_QUERY_NNZ) return fail(h, HR_ELIMIT, "query nnz %d exceeds HR_MAX_QUERY_NNZ", max_nnz);
+
+    std::shared_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    if (h->n_sparse == 0) {
+        std::fill(out_ids, out_ids + (size_t)B * k, (int64_t)-1);
+        std::fill(out_scores, out_scores + (size_t)B * k, 0.f);
+        return HR_OK;
+    }
+    Workspace* ws = take_ws(h);
+    if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
+    struct Giver { hr_index* h; Workspace* w; ~Giver() { give_ws(h, w); } } giver{h, ws};
+    hipStream_t s = ws->stream;
+    const size_t nnz = idx.size();
+    HIP_TRY(h, ws->d_qptr.ensure((size_t)(B + 1) * 8));
+    HIP_TRY(h, ws->d_qidx.ensure(std::max<size_t>(nnz, 1) * 4));
+    HIP_TRY(h, ws->d_qval.ensure(std::max<size_t>(nnz, 1) * 4));
+    HIP_TRY(h, ws->d_ids.ensure((size_t)B * k * 8));
+    HIP_TRY(h, ws->d_scores.ensure((size_t)B * k * 4));
+    HIP_TRY(h, ws->flags.ensure((size_t)B * 4));
+    HIP_TRY(h, hipMemcpyAsync(ws->d_qptr.p, ptr.data(), (size_t)(B + 1) * 8, hipMemcpyHostToDevice, s));
+    if (nnz) {
+        HIP_TRY(h, hipMemcpyAsync(ws->d_qidx.p, idx.data(), nnz * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(ws->d_qval.p, val.data(), nnz * 4, hipMemcpyHostToDevice, s));
+    }
+    const uint8_t* d_mask = nullptr;
+    if (rowmask) {
+        const size_t mb = (size_t)(h->n_sparse + 7) / 8;
+        HIP_TRY(h, ws->d_mask.ensure(mb));
+        HIP_TRY(h, hipMemcpyAsync(ws->d_mask.p, rowmask, mb, hipMemcpyHostToDevice, s));
+        d_mask = ws->d_mask.as<uint8_t>();
+    }
+    const int64_t n_groups = (h->n_sparse + kGroupRows - 1) / kGroupRows;
+    int C = candidate_groups_for_k(k);
+    std::vector<int32_t> flags(B);
+    for (;;) {
+        HR_TRY(sparse_search_enqueue(h, ws, s, ws->d_qptr.as<int64_t>(), ws->d_qidx.as<int32_t>(),
+                                     ws->d_qval.as<float>(), B, max_nnz, k, d_mask, ws->d_ids.as<int64_t>(),
+                                     ws->d_scores.as<float>(), ws->flags.as<int32_t>(), C));
+        HIP_TRY(h, hipMemcpyAsync(flags.data(), ws->flags.p, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        const bool all_exact = std::all_of(flags.begin(), flags.end(), [](int32_t f) { return f != 0; });
+        if (all_exact || C >= n_groups) break;
+        C = (int)std::min<int64_t>((int64_t)C * 4, round_up(n_groups, 16));
+    }
+    HIP_TRY(h, hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HR_OK;
+}
+
+int hr_fuse_rrf(hr_index* h, const int64_t* ids_a, int na, const int64_t* ids_b, int nb, const int64_t* ids_c, int nc,
+                double wa, double wb, double wc, int rrf_k, int64_t* out_ids, double* out_scores, int32_t* out_methods,
+                int32_t* n_out) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (na < 0 || nb < 0 || nc < 0 || na + nb + nc == 0) {
+        if (n_out) *n_out = 0;
+        return (na < 0 || nb < 0 || nc < 0) ? fail(h, HR_EINVAL, "negative list length") : HR_OK;
+    }
+    if (na > HR_MAX_TOPK || nb > HR_MAX_TOPK || nc > HR_MAX_TOPK)
+        return fail(h, HR_ELIMIT, "list longer than HR_MAX_TOPK=%d", HR_MAX_TOPK);
+    if (!out_ids || !out_scores || !out_methods || !n_out) return fail(h, HR_EINVAL, "null buffer");
+    DeviceGuard dg(h->device);
+    Workspace* ws = take_ws(h);
+    if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
+    struct Giver { hr_index* h; Workspace* w; ~Giver() { give_ws(h, w); } } giver{h, ws};
+    hipStream_t s = ws->stream;
+    const int total = na + nb + nc;
+    const int ka = std::max(na, 1);  // kernel wants a readable first list
+    std::vector<int64_t> staged((size_t)ka + nb + nc, -1);
+    if (na) std::memcpy(staged.data(), ids_a, (size_t)na * 8);
+    if (nb) std::memcpy(staged.data() + ka, ids_b, (size_t)nb * 8);
+    if (nc) std::memcpy(staged.data() + ka + nb, ids_c, (size_t)nc * 8);
+    HIP_TRY(h, ws->f_ids.ensure(staged.size() * 8));
+    HIP_TRY(h, ws->f_out_ids.ensure((size_t)total * 8));
+    HIP_TRY(h, ws->f_out_scores.ensure((size_t)total * 8));
+    HIP_TRY(h, ws->f_out_meth.ensure((size_t)total * 4));
+    HIP_TRY(h, ws->f_n.ensure(4));
+    HIP_TRY(h, hipMemcpyAsync(ws->f_ids.p, staged.data(), staged.size() * 8, hipMemcpyHostToDevice, s));
+    int64_t* d = ws->f_ids.as<int64_t>();
+    HR_TRY(hr_fuse_rrf_dev(d, ka, nb ? d + ka : nullptr, nb, nc ? d + ka + nb : nullptr, nc, 1, wa, wb, wc, rrf_k, total,
+                           ws->f_out_ids.as<int64_t>(), ws->f_out_scores.as<double>(), ws->f_out_meth.as<int32_t>(),
+                           ws->f_n.as<int32_t>(), s));
+    HIP_TRY(h, hipMemcpyAsync(out_ids, ws->f_out_ids.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(out_scores, ws->f_out_scores.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(out_methods, ws->f_out_meth.p, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(n_out, ws->f_n.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return HR_OK;
+}
+
+// ---- measurement hooks -----------------------------------------------------------------
+int hr_set_profiling(hr_index* h, int enabled) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    h->profiling = enabled;
+    return HR_OK;
+}
+
+int hr_last_kernel_ms(hr_index* h, float* out_ms, int n) {
+    if (!h || !out_ms || n < 2 * PH_COUNT) return fail(h, HR_EINVAL, "need room for %d floats", 2 * PH_COUNT);
+    DeviceGuard dg(h->device);
+    std::lock_guard<std::mutex> g(h->prof_mu);
+    double sum[PH_COUNT] = {0};
+    int cnt[PH_COUNT] = {0};
+    for (auto& sp : h->spans) {
+        float ms = 0.f;
+        if (hipEventSynchronize(sp.b) == hipSuccess && hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            sum[sp.phase] += ms;
+            cnt[sp.phase] += 1;
+        }
+        h->event_pool.push_back(sp.a);
+        h->event_pool.push_back(sp.b);
+    }
+    h->spans.clear();
+    // out[0..8] = mean ms per launch of each phase, out[9..17] = launches averaged
+    for (int p = 0; p < PH_COUNT; ++p) {
+        out_ms[p] = cnt[p] ? (float)(sum[p] / cnt[p]) : 0.f;
+        out_ms[PH_COUNT + p] = (float)cnt[p];
+    }
+    return HR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+/*
+ * hbmrag.h — C ABI of libhbmrag.so: the MI355X (gfx950) in-HBM shard store and
+ * hybrid-search kernels that replace the Milvus server behind
+ * advanced-rag-milvus's search hot path.
+ *
+ * The reference has no FFI of its own: its boundary is the duck-typed
+ * index-manager protocol that HybridRetriever consumes
+ * (reference src/advanced_rag/retrieval.py:341-419, :634-648) and that
+ * MilvusIndexManager implements by RPC to a Milvus server
+ * (reference src/advanced_rag/indexing.py:264-437 index_chunks,
+ * :439-551 search).  Every entry point below names the reference call it
+ * stands in for.  The Python host package (advanced-rag-milvus_amd/advanced_rag)
+ * binds these with ctypes; INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross this line;
+ *   - every function returns an hr_status (0 = ok) and never throws or aborts;
+ *     hr_last_error() gives the message for the last failure on that handle
+ *     (or, with NULL, the last failure of a call that had no handle);
+ *   - the caller owns every host buffer it passes in; the library owns all
+ *     device memory it allocates; `*_dev` entry points take DEVICE pointers
+ *     owned by the caller (e.g. torch tensors) and are asynchronous on the
+ *     given hipStream_t (passed as void*);
+ *   - results are written into caller-allocated arrays of size B*k, padded
+ *     with id -1 / score 0 when fewer than k rows qualify;
+ *   - row ids are int64 "global row numbers": local row + the shard's row
+ *     offset (hr_set_row_offset), so per-shard lists can be merged across GPUs;
+ *   - search calls are thread-safe against each other (each takes a private
+ *     workspace + stream from a pool); add/finalize take an exclusive lock.
+ *
+ * Result semantics (what the oracle in oracle/ restates bit-for-bit)
+ *   dense  : score32 = (float) S, S computed in fp64 by a k-ordered sequential
+ *            sum of exact products x[k]*q[k];  COSINE divides by
+ *            sqrt(sum x^2 * sum q^2) (0 when either norm is 0).  Rows are
+ *            ranked by (score32 desc, row id asc).  Milvus' HNSW(ef=64) is
+ *            approximate; this is the exact FLAT answer of the same metric.
+ *   sparse : score32 = (float) sum over the row's stored entries, in stored
+ *            (index) order, of value*query_value in fp64; only rows with
+ *            score32 > 0 qualify; same ranking rule.
+ *   fuse   : reciprocal-rank fusion exactly as reference
+ *            retrieval.py:421-491 (float64, k=60 by default, stable order).
+ */
+#ifndef HBMRAG_H
+#define HBMRAG_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(HR_BUILD)
+#define HR_API __attribute__((visibility("default")))
+#else
+#define HR_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hr_index hr_index; /* opaque shard handle (one per GPU / process) */
+
+typedef enum hr_status {
+    HR_OK = 0,
+    HR_EINVAL = 1, /* bad argument / shape; Python maps to ValueError            */
+    HR_ESTATE = 2, /* call not valid in this state (e.g. search before finalize) */
+    HR_EHIP = 3,   /* HIP runtime failure (message holds hipGetErrorString)      */
+    HR_ENOMEM = 4, /* host or device allocation failed                           */
+    HR_ELIMIT = 5  /* argument exceeds a compiled-in limit (see HR_MAX_*)        */
+} hr_status;
+
+enum { HR_F32 = 0, HR_F16 = 1 };               /* storage dtype of the dense shard */
+enum { HR_METRIC_IP = 0, HR_METRIC_COSINE = 1 }; /* dense metric_type                */
+enum { HR_METHOD_SEMANTIC = 1, HR_METHOD_SPARSE = 2, HR_METHOD_DOMAIN = 4 };
+
+#define HR_MAX_TOPK 256  /* reference clamps top_k to 100 and over-retrieves 2x (constants.py:47, retrieval.py:351) */
+#define HR_MAX_DIM 4096  /* dense dimension limit of the LDS-resident query tile */
+#define HR_MAX_QUERY_NNZ 4096
+
+/* ---- lifecycle -------------------------------------------------------------
+ * Replaces MilvusIndexManager._connect/_initialize_collections/_create_collection
+ * (reference indexing.py:134-262): one handle holds the "semantic_index"
+ * (dense) and "sparse_index" collections of one shard on one GPU.
+ * dim = 0 or sparse_dim = 0 disables that collection. */
+HR_API int hr_create(int device, int64_t dim, int dtype, int metric, int64_t sparse_dim, hr_index** out);
+HR_API void hr_destroy(hr_index* h);
+HR_API const char* hr_last_error(const hr_index* h);
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+HR_API int hr_version(void);
+
+/* Global id of local row 0 (multi-GPU row sharding; default 0). */
+HR_API int hr_set_row_offset(hr_index* h, int64_t first_row);
+/* Optional: pre-size the dense store so appends never reallocate. */
+HR_API int hr_reserve(hr_index* h, int64_t n_rows);
+
+/* ---- ingest ----------------------------------------------------------------
+ * Replaces Collection.insert on semantic_index / sparse_index
+ * (reference indexing.py:370-427).  Rows are appended; row numbers are
+ * assigned in call order.  hr_add_dense takes row-major fp32 rows and stores
+ * them in the shard's dtype (fp16: round-to-nearest-even, as numpy astype).
+ * hr_add_dense_raw takes rows already in the shard's dtype (fp16 bits as
+ * uint16).  The `_dev` forms take device pointers. */
+HR_API int hr_add_dense(hr_index* h, const float* rows, int64_t n);
+HR_API int hr_add_dense_raw(hr_index* h, const void* rows, int64_t n);
+HR_API int hr_add_dense_raw_dev(hr_index* h, const void* d_rows, int64_t n, void* stream);
+/* CSR batch: indptr[n+1], indices sorted ascending within a row, < sparse_dim
+ * (the {"indices","values"} payload of reference indexing.py:647-654, batched
+ * the way indexing.py:379-404 builds its scipy CSR). */
+HR_API int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n);
+/* Replaces Collection.flush/load (reference indexing.py:430-431, :259):
+ * computes row norms, builds the doc-range-partitioned postings, sizes the
+ * search workspaces.  May be called again after further adds. */
+HR_API int hr_finalize(hr_index* h);
+
+HR_API int64_t hr_num_rows(const hr_index* h);        /* dense rows (Collection.num_entities, indexing.py:687) */
+HR_API int64_t hr_num_sparse_rows(const hr_index* h);
+HR_API int64_t hr_device_bytes(const hr_index* h);    /* HBM held by the shard */
+
+/* ---- search (host buffers, synchronous) --------------------------------------
+ * Replace Collection.search on "semantic_index" / "sparse_index"
+ * (reference indexing.py:503-525) for a batch of B queries.
+ *   q        [B*dim] fp32 query vectors
+ *   rowmask  optional bitmask over local rows, 1 bit per row (bit r%8 of byte
+ *            r/8), 1 = row passes the filter expression; NULL = all rows
+ *   out_ids  [B*k] int64, out_scores [B*k] fp32, best first. */
+HR_API int hr_search_dense(hr_index* h, const float* q, int B, int k, const uint8_t* rowmask,
+                    int64_t* out_ids, float* out_scores);
+/* Sparse queries as CSR (q_indptr[B+1]); drop_ratio = Milvus
+ * drop_ratio_search (reference retrieval.py:97-101): the
+ * floor(drop_ratio*nnz) smallest-|value| entries of each query are ignored. */
+HR_API int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
+                     int B, int k, float drop_ratio, const uint8_t* rowmask,
+                     int64_t* out_ids, float* out_scores);
+
+/* Reciprocal-rank fusion of up to three ranked id lists of ONE query
+ * (reference HybridRetriever._fuse_results, retrieval.py:421-491), executed
+ * by the device kernel.  ids < 0 end a list.  out arrays hold na+nb+nc
+ * entries; *n_out receives the number of fused ids. */
+HR_API int hr_fuse_rrf(hr_index* h, const int64_t* ids_a, int na, const int64_t* ids_b, int nb,
+                const int64_t* ids_c, int nc, double wa, double wb, double wc, int rrf_k,
+                int64_t* out_ids, double* out_scores, int32_t* out_methods, int32_t* n_out);
+
+/* ---- search (device buffers, asynchronous on `stream`) -------------------------
+ * Same results as the host forms.  d_flags[B] (optional) receives 1 when the
+ * candidate-generation bound proves the list exact, 0 when the caller must
+ * re-run that query through the host form (which escalates by itself). */
+/* The sparse form takes queries already reduced (drop_ratio applied) and
+ * sorted by index, as CSR; max_q_nnz = the longest query (sets the scan's
+ * rounding bound). */
+HR_API int hr_search_dense_dev(hr_index* h, const float* d_q, int B, int k, const uint8_t* d_rowmask,
+                        int64_t* d_ids, float* d_scores, int32_t* d_flags, void* stream);
+HR_API int hr_search_sparse_dev(hr_index* h, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                         const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
+                         const uint8_t* d_rowmask, int64_t* d_ids, float* d_scores,
+                         int32_t* d_flags, void* stream);
+/* Batched RRF: lists are [B][ka], [B][kb], [B][kc] (kc = 0 / NULL for none);
+ * outputs [B][top_k] ids / fp64 scores / method bitmasks and d_n_out[B]. */
+HR_API int hr_fuse_rrf_dev(const int64_t* d_ids_a, int ka, const int64_t* d_ids_b, int kb,
+                    const int64_t* d_ids_c, int kc, int B, double wa, double wb, double wc,
+                    int rrf_k, int top_k, int64_t* d_out_ids, double* d_out_scores,
+                    int32_t* d_out_methods, int32_t* d_n_out, void* stream);
+/* Cross-shard merge after the RCCL all-gather: n_lists per-shard lists of
+ * k_in (score, id) pairs per query, layout [n_lists][B][k_in]; output the
+ * best k_out by (score desc, id asc).  (No reference analogue: Milvus merges
+ * its num_shards=4 segments server-side, indexing.py:234-239.) */
+HR_API int hr_merge_topk_dev(const float* d_scores, const int64_t* d_ids, int n_lists, int B, int k_in,
+                      int k_out, int64_t* d_out_ids, float* d_out_scores, void* stream);
+
+/* ---- measurement hooks -------------------------------------------------------
+ * hr_set_profiling(1) brackets every dense-scan and sparse-scan launch with
+ * HIP events on the stream it is launched on; (2) brackets all nine phases:
+ * [0] query prep, [1] dense scan, [2] group select, [3] refine, [4] top-k,
+ * [5] sparse scan, [6] sparse select, [7] sparse refine, [8] sparse top-k.
+ * hr_last_kernel_ms drains the recorded spans: out_ms[p] = mean ms per launch
+ * of phase p since the previous call, out_ms[HR_N_PHASES + p] = launches
+ * averaged.  n must be >= 2*HR_N_PHASES. */
+#define HR_N_PHASES 9
+HR_API int hr_set_profiling(hr_index* h, int enabled);
+HR_API int hr_last_kernel_ms(hr_index* h, float* out_ms, int n);
+/* Algorithmic bytes one dense scan launch reads (rows*dim*sizeof(elem) + 4*rows). */
+HR_API int64_t hr_dense_scan_bytes(const hr_index* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBMRAG_H */

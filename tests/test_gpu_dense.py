@@ -1,0 +1,98 @@
+"""Dense parity: HIP scan + refine (through the C ABI) vs the canonical CPU oracle.
+ids must match bit-for-bit and scores bit-for-bit (both sides compute the same
+k-ordered fp64 sum and round once to fp32)."""
+import numpy as np
+import pytest
+
+import oracle
+from advanced_rag import _native as nat
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _check(h, X, Q, k, metric, mask=None):
+    ids, sc = h.search_dense(Q, k, mask)
+    oids, osc = oracle.dense_search(X, Q, k, metric, mask)
+    assert np.array_equal(ids, oids), f"ids differ: {np.argwhere(ids != oids)[:5]}"
+    assert np.array_equal(_bits(sc), _bits(osc))
+
+
+@pytest.mark.parametrize("dtype,np_dtype", [(nat.HR_F16, np.float16), (nat.HR_F32, np.float32)])
+@pytest.mark.parametrize("metric", [nat.HR_METRIC_COSINE, nat.HR_METRIC_IP])
+@pytest.mark.parametrize("n,d,B,k", [(1000, 384, 1, 40), (1000, 384, 7, 20), (5000, 96, 33, 40), (64, 128, 3, 100),
+                                     (20000, 768, 64, 40), (3, 100, 2, 5)])
+def test_dense_matches_oracle(gpu, dtype, np_dtype, metric, n, d, B, k):
+    rng = np.random.default_rng(n + d + B)
+    X = rng.standard_normal((n, d)).astype(np.float32).astype(np_dtype)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    h = nat.ShardHandle(d, dtype, metric)
+    h.add_dense(X)
+    h.finalize()
+    _check(h, X, Q, k, metric)
+    h.close()
+
+
+def test_config2_100k_384_fp32(gpu):
+    """BASELINE config 2: 100k x 384 fp32, dense IP/COSINE brute force, top_k=20 (k'=40)."""
+    rng = np.random.default_rng(1234)
+    X = rng.standard_normal((100_000, 384)).astype(np.float32)
+    Q = np.random.default_rng(4321).standard_normal((8, 384)).astype(np.float32)
+    for metric in (nat.HR_METRIC_COSINE, nat.HR_METRIC_IP):
+        h = nat.ShardHandle(384, nat.HR_F32, metric)
+        h.add_dense(X)
+        h.finalize()
+        _check(h, X, Q, 40, metric)
+        h.close()
+
+
+def test_incremental_add_and_rowmask(gpu):
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((3001, 200)).astype(np.float16)
+    Q = rng.standard_normal((5, 200)).astype(np.float32)
+    h = nat.ShardHandle(200, nat.HR_F16, nat.HR_METRIC_COSINE)
+    for a, b in ((0, 1), (1, 18), (18, 1500), (1500, 3001)):  # ragged appends, none aligned to 16
+        h.add_dense(X[a:b])
+    h.finalize()
+    _check(h, X, Q, 40, nat.HR_METRIC_COSINE)
+    allow = rng.random(3001) < 0.3
+    mask = np.packbits(allow, bitorder="little")
+    _check(h, X, Q, 40, nat.HR_METRIC_COSINE, mask)
+    none = np.zeros_like(mask)
+    ids, _ = h.search_dense(Q, 10, none)
+    assert (ids == -1).all()
+    h.close()
+
+
+def test_duplicates_and_zero_rows_tie_rule(gpu):
+    """Equal scores must come back in ascending row order; zero rows score 0 under COSINE."""
+    rng = np.random.default_rng(3)
+    base = rng.standard_normal((50, 64)).astype(np.float16)
+    X = np.concatenate([base, base, np.zeros((20, 64), np.float16), base])
+    Q = np.concatenate([base[:3].astype(np.float32), np.zeros((1, 64), np.float32)])
+    for metric in (nat.HR_METRIC_COSINE, nat.HR_METRIC_IP):
+        h = nat.ShardHandle(64, nat.HR_F16, metric)
+        h.add_dense(X)
+        h.finalize()
+        _check(h, X, Q, 30, metric)
+        h.close()
+
+
+def test_errors(gpu):
+    h = nat.ShardHandle(32, nat.HR_F16, nat.HR_METRIC_COSINE)
+    with pytest.raises(nat.HbmRagError):
+        h.search_dense(np.zeros((1, 32), np.float32), 5)  # before finalize
+    h.add_dense(np.ones((4, 32), np.float16))
+    h.finalize()
+    with pytest.raises(ValueError):
+        h.search_dense(np.zeros((1, 32), np.float32), 0)
+    with pytest.raises(nat.HbmRagError):
+        h.search_dense(np.zeros((1, 32), np.float32), 10_000)
+    ids, sc = h.search_dense(np.ones((1, 32), np.float32), 8)
+    assert ids[0, :4].tolist() == [0, 1, 2, 3] and (ids[0, 4:] == -1).all()
+    h.close()
+    with pytest.raises(ValueError):
+        nat.ShardHandle(0, nat.HR_F16, nat.HR_METRIC_COSINE, 0)
