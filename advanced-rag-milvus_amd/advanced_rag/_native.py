@@ -68,8 +68,11 @@ _SIGNATURES = {
     "hr_fuse_rrf_dev": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int,
                                    _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
-    "hr_merge_topk_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
-                                     _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_merge_topk_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                                     _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_rerank_linear_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
+                                        _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p,
+                                        _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "hr_set_profiling": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "hr_last_kernel_ms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int]),
 }
@@ -277,13 +280,29 @@ def fuse_rrf_dev(d_a: int, ka: int, d_b: int, kb: int, d_c: int, kc: int, B: int
         raise HbmRagError(rc, msg)
 
 
+def _raise_global(L, rc: int):
+    msg = (L.hr_last_error(None) or b"").decode()
+    if rc == 1:
+        raise ValueError(msg)
+    raise HbmRagError(rc, msg)
+
+
 def merge_topk_dev(d_scores: int, d_ids: int, n_lists: int, B: int, k_in: int, k_out: int, d_out_ids: int,
-                   d_out_scores: int, stream: int = 0):
+                   d_out_scores: int, stream: int = 0, score_stride: int = 0, id_stride: int = 0):
     L = load_library()
-    rc = L.hr_merge_topk_dev(_vp(d_scores), _vp(d_ids), n_lists, B, k_in, k_out, _vp(d_out_ids), _vp(d_out_scores),
-                             _vp(stream) if stream else None)
+    rc = L.hr_merge_topk_dev(_vp(d_scores), _vp(d_ids), n_lists, score_stride or B * k_in, id_stride or B * k_in, B,
+                             k_in, k_out, _vp(d_out_ids), _vp(d_out_scores), _vp(stream) if stream else None)
     if rc != 0:
-        msg = (L.hr_last_error(None) or b"").decode()
-        if rc == 1:
-            raise ValueError(msg)
-        raise HbmRagError(rc, msg)
+        _raise_global(L, rc)
+
+
+def rerank_linear_dev(d_ids: int, d_scores: int, d_methods: int, d_n: int, B: int, k_in: int, base_w: float,
+                      method_bonus: float, recency_w: float, k_out: int, d_out_ids: int, d_out_scores: int,
+                      d_out_orig: int, stream: int = 0, d_recency: int = 0):
+    L = load_library()
+    rc = L.hr_rerank_linear_dev(_vp(d_ids), _vp(d_scores), _vp(d_methods), _vp(d_n),
+                                _vp(d_recency) if d_recency else None, B, k_in, base_w, method_bonus, recency_w,
+                                k_out, _vp(d_out_ids), _vp(d_out_scores), _vp(d_out_orig),
+                                _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)

@@ -1,0 +1,172 @@
+"""Batched, device-resident hybrid search over a row-sharded corpus.
+
+This is the throughput path behind `retrieve()` for B concurrent queries (the
+reference serves up to 64 in-flight retrieve() calls, service.py:137,149): one
+pass of  dense top-k' + sparse top-k' -> [all-gather over RCCL/xGMI + merge] ->
+RRF -> learned-ranker rerank,  every step a HIP kernel of libhbmrag enqueued on
+the caller's stream; PyTorch only provides the device buffers, the stream and
+`torch.distributed` (backend "nccl" = RCCL).
+
+Sharding: rank r of W owns rows [r*ceil(N/W), ...) — its shard
+handle was created with that row offset, so local lists already carry global
+row ids.  Per batch each rank runs its local searches, then ONE all-gather of a
+packed buffer (both modalities' ids + scores: 2*B*k'*12 bytes per rank — a
+latency-bound exchange, far below per-link xGMI bandwidth), then every rank
+merges the W lists with the same (score desc, id asc) rule, so all ranks hold
+identical fused results without a second collective.
+
+Semantics mirror HybridRetriever._retrieve_inner/_fuse_results/rerank
+(reference retrieval.py:249-339, :421-491, :518-563) with profile "default":
+k' = 2*top_k per modality, weights dense/sparse, RRF k = 60, fused[:top_k],
+then rerank to rerank_top_k with LearnedRanker's linear score.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _native as nat
+
+
+def shard_range(n_rows: int, rank: int, world: int, align: int = 1) -> Tuple[int, int]:
+    """Contiguous row range of `rank`: ceil(n/world) rows each, rounded up to `align`."""
+    per = -(-n_rows // world)
+    per = -(-per // align) * align
+    lo = min(n_rows, rank * per)
+    return lo, min(n_rows, lo + per)
+
+
+def pack_sparse_queries(queries: Sequence[Tuple[Sequence[int], Sequence[float]]], drop_ratio: float = 0.0):
+    """Host prep of a sparse query batch for the device form: apply
+    drop_ratio_search (smallest |value| first; among equals the later entry),
+    sort by index, build CSR.  Returns (indptr int64, idx int32, val float32, max_nnz)."""
+    ptr = [0]
+    idx_parts, val_parts = [], []
+    max_nnz = 0
+    for qi, qv in queries:
+        qi = np.asarray(qi, dtype=np.int32)
+        qv = np.asarray(qv, dtype=np.float32)
+        n_drop = int(np.floor(drop_ratio * len(qi)))
+        if n_drop:
+            order = np.lexsort((-np.arange(len(qi)), np.abs(qv)))  # |v| asc, later entry first
+            keep = np.sort(order[n_drop:])
+            qi, qv = qi[keep], qv[keep]
+        order = np.argsort(qi, kind="stable")
+        idx_parts.append(qi[order])
+        val_parts.append(qv[order])
+        ptr.append(ptr[-1] + len(qi))
+        max_nnz = max(max_nnz, len(qi))
+    idx = np.concatenate(idx_parts) if idx_parts else np.zeros(0, np.int32)
+    val = np.concatenate(val_parts) if val_parts else np.zeros(0, np.float32)
+    return np.asarray(ptr, np.int64), idx.astype(np.int32), val.astype(np.float32), max_nnz
+
+
+@dataclass
+class EngineConfig:
+    top_k: int = 20
+    rerank_top_k: int = 5
+    dense_weight: float = 0.7
+    sparse_weight: float = 0.3
+    rrf_k: int = 60
+    enable_reranking: bool = True
+    base_weight: float = 1.0      # LearnedRankerConfig defaults (ranker.py:27-30)
+    method_bonus: float = 0.1
+    recency_weight: float = 0.0
+    use_sparse: bool = True
+
+
+class HybridSearchEngine:
+    def __init__(self, handle: "nat.ShardHandle", config: Optional[EngineConfig] = None, process_group=None,
+                 device: Optional[str] = None):
+        import torch
+        self.torch = torch
+        self.h = handle
+        self.cfg = config or EngineConfig()
+        self.group = process_group
+        self.dist = None
+        self.world, self.rank = 1, 0
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.dist = torch.distributed
+            self.world = self.dist.get_world_size(process_group)
+            self.rank = self.dist.get_rank(process_group)
+        self.device = torch.device(device or f"cuda:{handle.device}")
+        self._bufs: Dict[int, dict] = {}
+
+    # ------------------------------------------------------------------ buffers
+    def _buffers(self, B: int) -> dict:
+        b = self._bufs.get(B)
+        if b is not None:
+            return b
+        t, dev, cfg = self.torch, self.device, self.cfg
+        kp = 2 * cfg.top_k
+        n_mod = 2 if cfg.use_sparse else 1
+        id_bytes, sc_bytes = n_mod * B * kp * 8, n_mod * B * kp * 4
+        pack = t.zeros(id_bytes + sc_bytes, dtype=t.uint8, device=dev)
+        b = {
+            "kp": kp, "n_mod": n_mod, "pack": pack, "id_bytes": id_bytes,
+            "ids": pack[:id_bytes].view(t.int64).view(n_mod, B, kp),
+            "scores": pack[id_bytes:].view(t.float32).view(n_mod, B, kp),
+            "flags": t.zeros((n_mod, B), dtype=t.int32, device=dev),
+            "fused_ids": t.empty((B, cfg.top_k), dtype=t.int64, device=dev),
+            "fused_scores": t.empty((B, cfg.top_k), dtype=t.float64, device=dev),
+            "fused_methods": t.empty((B, cfg.top_k), dtype=t.int32, device=dev),
+            "fused_n": t.empty((B,), dtype=t.int32, device=dev),
+            "rr_ids": t.empty((B, cfg.rerank_top_k), dtype=t.int64, device=dev),
+            "rr_scores": t.empty((B, cfg.rerank_top_k), dtype=t.float64, device=dev),
+            "rr_orig": t.empty((B, cfg.rerank_top_k), dtype=t.float64, device=dev),
+        }
+        if self.world > 1:
+            b["gathered"] = t.empty((self.world, id_bytes + sc_bytes), dtype=t.uint8, device=dev)
+            b["m_ids"] = t.empty((n_mod, B, kp), dtype=t.int64, device=dev)
+            b["m_scores"] = t.empty((n_mod, B, kp), dtype=t.float32, device=dev)
+        self._bufs[B] = b
+        return b
+
+    # ------------------------------------------------------------------ one batch
+    def search(self, q, sparse=None) -> dict:
+        """q: float32 [B, dim] device tensor.  sparse: (indptr int64[B+1], idx int32, val float32, max_nnz)
+        device tensors from `upload_sparse`.  Asynchronous on the current stream; returns the
+        buffer dict (fused_* and rr_* tensors are the results; they are reused by the next call)."""
+        t, cfg = self.torch, self.cfg
+        B = q.shape[0]
+        b = self._buffers(B)
+        kp = b["kp"]
+        stream = t.cuda.current_stream(self.device).cuda_stream
+        self.h.search_dense_dev(q.data_ptr(), B, kp, b["ids"][0].data_ptr(), b["scores"][0].data_ptr(),
+                                b["flags"][0].data_ptr(), 0, stream)
+        if cfg.use_sparse:
+            indptr, idx, val, max_nnz = sparse
+            self.h.search_sparse_dev(indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, int(idx.shape[0]),
+                                     int(max_nnz), kp, b["ids"][1].data_ptr(), b["scores"][1].data_ptr(),
+                                     b["flags"][1].data_ptr(), 0, stream)
+        ids, scores = b["ids"], b["scores"]
+        if self.world > 1:
+            g = b["gathered"]
+            self.dist.all_gather_into_tensor(g.view(-1), b["pack"], group=self.group)
+            total = g.shape[1]
+            for m in range(b["n_mod"]):
+                id_off = m * B * kp * 8
+                sc_off = b["id_bytes"] + m * B * kp * 4
+                nat.merge_topk_dev(g.data_ptr() + sc_off, g.data_ptr() + id_off, self.world, B, kp, kp,
+                                   b["m_ids"][m].data_ptr(), b["m_scores"][m].data_ptr(), stream,
+                                   score_stride=total // 4, id_stride=total // 8)
+            ids, scores = b["m_ids"], b["m_scores"]
+        nat.fuse_rrf_dev(ids[0].data_ptr(), kp, ids[1].data_ptr() if cfg.use_sparse else 0,
+                         kp if cfg.use_sparse else 0, 0, 0, B, cfg.dense_weight, cfg.sparse_weight, 0.2, cfg.rrf_k,
+                         cfg.top_k, b["fused_ids"].data_ptr(), b["fused_scores"].data_ptr(),
+                         b["fused_methods"].data_ptr(), b["fused_n"].data_ptr(), stream)
+        if cfg.enable_reranking:
+            nat.rerank_linear_dev(b["fused_ids"].data_ptr(), b["fused_scores"].data_ptr(),
+                                  b["fused_methods"].data_ptr(), b["fused_n"].data_ptr(), B, cfg.top_k,
+                                  cfg.base_weight, cfg.method_bonus, cfg.recency_weight, cfg.rerank_top_k,
+                                  b["rr_ids"].data_ptr(), b["rr_scores"].data_ptr(), b["rr_orig"].data_ptr(), stream)
+        b["list_ids"], b["list_scores"] = ids, scores
+        return b
+
+    def upload_sparse(self, packed):
+        t = self.torch
+        indptr, idx, val, max_nnz = packed
+        return (t.from_numpy(indptr).to(self.device), t.from_numpy(idx).to(self.device),
+                t.from_numpy(val).to(self.device), max_nnz)

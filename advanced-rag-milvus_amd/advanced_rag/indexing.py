@@ -1,0 +1,476 @@
+"""In-HBM shard store behind the reference's index-manager protocol.
+
+`MilvusIndexManager` here is a drop-in for the reference class of the same name
+(reference src/advanced_rag/indexing.py:80-713) with the Milvus server replaced
+by libhbmrag: the three collections ("semantic_index" dense/COSINE,
+"sparse_index" sparse/IP, "domain_index" dense/COSINE; indexing.py:143-180)
+live in the HBM of one GPU as a tiled fp16/fp32 matrix plus doc-range postings,
+and `search` runs the HIP kernels instead of an RPC (indexing.py:503-525).
+Host and port are accepted and ignored.  Payload columns (content, ids, scalar
+fields of the schema, indexing.py:191-225) stay on the host, keyed by row.
+
+Protocol consumed by HybridRetriever (retrieval.py:348-354, :634-648):
+  async _generate_semantic_embedding(text) -> float32[dim]
+  async _generate_sparse_embedding(text)   -> {"indices","values"} | ndarray
+  async _generate_domain_embedding(text, domain)
+  async search(query_embedding, collection_name, top_k, filters, search_params)
+        -> [{id, content, score, metadata{doc_id, chunk_index, entropy,
+             redundancy, domain_density, timestamp}}]   (best first)
+plus index_chunks / get_collection_stats / delete_by_filter / close.
+"""
+from __future__ import annotations
+
+import asyncio
+import logging
+import os
+from concurrent.futures import ThreadPoolExecutor
+from dataclasses import dataclass
+from enum import Enum
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import filters as _filters
+from .constants import IndexingConstants
+from .embedding_cache import get_semantic_cache
+
+logger = logging.getLogger(__name__)
+
+
+class IndexType(Enum):
+    SEMANTIC = "semantic"
+    SPARSE = "sparse"
+    DOMAIN = "domain"
+    HYBRID = "hybrid"
+
+
+@dataclass
+class IndexConfig:
+    collection_name: str
+    dimension: int
+    index_type: str = "HNSW"   # accepted for compatibility; the store is always exact FLAT
+    metric_type: str = "L2"
+    index_params: Optional[Dict] = None
+    enable_dynamic_field: bool = True
+
+    def __post_init__(self):
+        if self.index_params is None:
+            self.index_params = {"M": 16, "efConstruction": 200}
+
+
+class ShardCollection:
+    """What `manager.collections[name]` holds: a named view of one shard handle
+    with the handful of Collection methods the reference calls
+    (num_entities / flush / load / release / delete, indexing.py:259, :430, :683-701)."""
+
+    def __init__(self, manager: "MilvusIndexManager", name: str, kind: str, handle, dim: int, metric: str):
+        self.manager, self.name, self.kind, self.handle, self.dim, self.metric = manager, name, kind, handle, dim, metric
+
+    @property
+    def num_entities(self) -> int:
+        return self.handle.num_sparse_rows if self.kind == "sparse" else self.handle.num_rows
+
+    @property
+    def schema(self) -> str:
+        return (f"ShardCollection({self.name}, kind={self.kind}, dim={self.dim}, metric={self.metric}, "
+                "fields=[id, chunk_id, doc_id, content, chunk_index, token_count, entropy, redundancy, "
+                "domain_density, embedding, metadata_json, timestamp])")
+
+    @property
+    def indexes(self) -> List[str]:
+        return [f"FLAT/{self.metric} (exact scan, gfx950)"]
+
+    def flush(self):
+        self.handle.finalize()
+
+    load = flush
+
+    def release(self):
+        return None
+
+    def delete(self, expr: str):
+        self.manager._tombstone(expr)
+
+
+class MilvusIndexManager:
+    def __init__(self, host: str = "localhost", port: int = 19530, enable_sharding: bool = True, num_shards: int = 4,
+                 semantic_dim: int = 1536, sparse_dim: int = 10000, domain_dim: int = 768, connect: bool = True,
+                 *, dtype: str = "float16", device: int = 0, enable_domain: bool = True):
+        self.host, self.port = host, port
+        self.enable_sharding, self.num_shards = enable_sharding, num_shards
+        self.semantic_dim, self.sparse_dim, self.domain_dim = semantic_dim, sparse_dim, domain_dim
+        self.dtype, self.device, self.enable_domain = dtype, device, enable_domain
+        self.collections: Dict[str, ShardCollection] = {}
+        self.embedding_generator = None
+        self.embedding_executor = ThreadPoolExecutor(max_workers=IndexingConstants.THREAD_POOL_WORKERS,
+                                                     thread_name_prefix="embedding-")
+        self._main = None      # ShardHandle: semantic + sparse
+        self._domain = None    # ShardHandle: domain
+        self._cols: Dict[str, list] = {k: [] for k in ("id", "doc_id", "content", "chunk_index", "token_count",
+                                                       "entropy", "redundancy", "domain_density", "timestamp",
+                                                       "metadata_json")}
+        self._np_cols: Optional[Dict[str, np.ndarray]] = None
+        self._deleted: Optional[np.ndarray] = None
+        self._synthetic_rows = 0   # rows whose payload is derived from the row number (bulk/benchmark ingest)
+        if connect:
+            self._connect()
+            self._initialize_collections()
+
+    # ------------------------------------------------------------------ lifecycle
+    def _connect(self):
+        from . import _native
+        self._native = _native
+        _native.load_library()
+
+    def _initialize_collections(self):
+        nat = self._native
+        store = nat.HR_F16 if self.dtype in ("float16", "fp16", "f16") else nat.HR_F32
+        sparse_on = os.getenv("ENABLE_SPARSE", "1") == "1"
+        self._main = nat.ShardHandle(self.semantic_dim, store, nat.HR_METRIC_COSINE,
+                                     self.sparse_dim if sparse_on else 0, self.device)
+        self.collections["semantic_index"] = ShardCollection(self, "semantic_index", "dense", self._main,
+                                                             self.semantic_dim, "COSINE")
+        if sparse_on:
+            self.collections["sparse_index"] = ShardCollection(self, "sparse_index", "sparse", self._main,
+                                                               self.sparse_dim, "IP")
+        if self.enable_domain:
+            self._domain = nat.ShardHandle(self.domain_dim, store, nat.HR_METRIC_COSINE, 0, self.device)
+            self.collections["domain_index"] = ShardCollection(self, "domain_index", "dense", self._domain,
+                                                               self.domain_dim, "COSINE")
+
+    # ------------------------------------------------------------------ host columns
+    def _columns(self) -> Dict[str, np.ndarray]:
+        if self._np_cols is None:
+            c = self._cols
+            self._np_cols = {
+                "id": np.asarray(c["id"], dtype=str), "chunk_id": np.asarray(c["id"], dtype=str),
+                "doc_id": np.asarray(c["doc_id"], dtype=str), "timestamp": np.asarray(c["timestamp"], dtype=str),
+                "chunk_index": np.asarray(c["chunk_index"], dtype=np.int64),
+                "token_count": np.asarray(c["token_count"], dtype=np.int64),
+                "entropy": np.asarray(c["entropy"], dtype=np.float32),
+                "redundancy": np.asarray(c["redundancy"], dtype=np.float32),
+                "domain_density": np.asarray(c["domain_density"], dtype=np.float32),
+            }
+        return self._np_cols
+
+    @property
+    def num_rows(self) -> int:
+        return self._synthetic_rows or len(self._cols["id"])
+
+    @staticmethod
+    def synthetic_id(row: int) -> str:
+        """String id of a bulk-ingested row: doc{row//10}::{row%10}::{row:08x}."""
+        return f"doc{row // 10}::{row % 10}::{row:08x}"
+
+    def _row_mask(self, expr: Optional[str]) -> Optional[np.ndarray]:
+        if self._synthetic_rows:
+            if expr:
+                raise ValueError("filter expressions need payload columns; this shard was bulk-ingested without them")
+            return None
+        n = self.num_rows
+        keep = None
+        if expr:
+            keep = _filters.evaluate(expr, self._columns(), n)
+        if self._deleted is not None and self._deleted[:n].any():
+            alive = ~self._deleted[:n]
+            keep = alive if keep is None else (keep & alive)
+        return None if keep is None else _filters.pack(keep)
+
+    def _tombstone(self, expr: str):
+        n = self.num_rows
+        hit = _filters.evaluate(expr, self._columns(), n)
+        if self._deleted is None or self._deleted.shape[0] < n:
+            grown = np.zeros(n, dtype=bool)
+            if self._deleted is not None:
+                grown[:self._deleted.shape[0]] = self._deleted
+            self._deleted = grown
+        self._deleted[:n] |= hit
+
+    # ------------------------------------------------------------------ ingest
+    async def index_chunks(self, chunks: List["Chunk"], domain: Optional[str] = None) -> Dict[str, Any]:
+        """Embed and append chunks to every collection (reference indexing.py:264-437);
+        same summary keys, same best-effort handling of sparse/domain failures."""
+        summary = {"total_chunks": len(chunks), "indexed_semantic": 0, "indexed_sparse": 0, "indexed_domain": 0,
+                   "errors": []}
+        use_sparse = "sparse_index" in self.collections and os.getenv("ENABLE_SPARSE", "1") == "1"
+        dense_vecs = await self._generate_semantic_embeddings_batch([c.text for c in chunks])
+        rows_dense, rows_domain, sp_ptr, sp_idx, sp_val, kept = [], [], [0], [], [], []
+        n_sparse_ok = 0
+        for i, chunk in enumerate(chunks):
+            try:
+                dense = np.asarray(dense_vecs[i], dtype=np.float32).reshape(-1)
+                if dense.shape[0] != self.semantic_dim:
+                    raise ValueError(f"semantic embedding has dim {dense.shape[0]}, expected {self.semantic_dim}")
+                sp = None
+                if use_sparse:
+                    try:
+                        sp = self._as_sparse_payload(await self._generate_sparse_embedding(chunk.text, role="document"))
+                        n_sparse_ok += 1
+                    except Exception as e:
+                        summary["errors"].append({"chunk_id": chunk.metadata.chunk_id,
+                                                  "error": f"sparse_embedding_failed: {e}"})
+                dom = None
+                if "domain_index" in self.collections:
+                    dom = np.asarray(await self._generate_domain_embedding(chunk.text, domain),
+                                     dtype=np.float32).reshape(-1)
+                    if dom.shape[0] != self.domain_dim:
+                        raise ValueError(f"domain embedding has dim {dom.shape[0]}, expected {self.domain_dim}")
+            except Exception as e:
+                summary["errors"].append({"chunk_id": chunk.metadata.chunk_id, "error": str(e)})
+                continue
+            rows_dense.append(dense)
+            if dom is not None:
+                rows_domain.append(dom)
+            if use_sparse:  # a row per chunk keeps row numbers aligned across collections
+                si, sv = sp if sp is not None else (np.zeros(0, np.int32), np.zeros(0, np.float32))
+                sp_idx.append(si)
+                sp_val.append(sv)
+                sp_ptr.append(sp_ptr[-1] + len(si))
+            kept.append(chunk)
+        if not kept:
+            return summary
+        try:
+            if "semantic_index" not in self.collections:
+                raise KeyError("semantic_index")
+            await asyncio.to_thread(self._main.add_dense, np.stack(rows_dense))
+            summary["indexed_semantic"] = len(kept)
+            if use_sparse:
+                try:
+                    await asyncio.to_thread(self._main.add_sparse, np.asarray(sp_ptr, np.int64),
+                                            np.concatenate(sp_idx) if sp_idx else np.zeros(0, np.int32),
+                                            np.concatenate(sp_val) if sp_val else np.zeros(0, np.float32))
+                    summary["indexed_sparse"] = n_sparse_ok
+                except Exception as e:
+                    logger.warning("Sparse insert failed; continuing without sparse index: %s", e)
+                    summary["errors"].append({"insert_sparse_error": str(e)})
+            if rows_domain:
+                await asyncio.to_thread(self._domain.add_dense, np.stack(rows_domain))
+                summary["indexed_domain"] = len(rows_domain)
+            for chunk in kept:
+                m = chunk.metadata
+                c = self._cols
+                c["id"].append(m.chunk_id)
+                c["doc_id"].append(str(m.doc_id))
+                c["content"].append(chunk.text[:65535])
+                c["chunk_index"].append(int(m.chunk_index))
+                c["token_count"].append(int(m.token_count))
+                c["entropy"].append(float(m.entropy))
+                c["redundancy"].append(float(m.redundancy))
+                c["domain_density"].append(float(m.domain_density))
+                c["timestamp"].append(str(m.timestamp))
+                c["metadata_json"].append(str(m.to_dict())[:10000])
+            self._np_cols = None
+            for coll in {id(c.handle): c for c in self.collections.values()}.values():
+                await asyncio.to_thread(coll.flush)
+        except Exception as e:
+            summary["errors"].append({"insert_error": str(e)})
+        return summary
+
+    def add_rows(self, dense: np.ndarray, sparse_csr=None, ids: Optional[Sequence[str]] = None,
+                 contents: Optional[Sequence[str]] = None, **scalar_columns):
+        """Bulk ingest of pre-computed vectors (benchmarks, snapshots): dense [n, dim]
+        float16/float32, optional CSR triple (indptr, indices, values)."""
+        if self._synthetic_rows:
+            raise ValueError("shard is in synthetic-payload mode; use add_rows_synthetic")
+        n = dense.shape[0]
+        base = self.num_rows
+        self._main.add_dense(dense)
+        if sparse_csr is not None and "sparse_index" in self.collections:
+            self._main.add_sparse(*sparse_csr)
+        c = self._cols
+        c["id"].extend(ids if ids is not None else [f"doc{(base + r) // 10}::{(base + r) % 10}::{base + r:08x}"
+                                                    for r in range(n)])
+        c["content"].extend(contents if contents is not None else [""] * n)
+        defaults = {"doc_id": lambda r: f"doc{(base + r) // 10}", "chunk_index": lambda r: (base + r) % 10,
+                    "token_count": lambda r: 0, "entropy": lambda r: 0.0, "redundancy": lambda r: 0.0,
+                    "domain_density": lambda r: 0.0, "timestamp": lambda r: "", "metadata_json": lambda r: ""}
+        for name, fn in defaults.items():
+            given = scalar_columns.get(name)
+            c[name].extend(list(given) if given is not None else [fn(r) for r in range(n)])
+        self._np_cols = None
+
+    def add_rows_synthetic(self, dense: np.ndarray, sparse_csr=None):
+        """Bulk ingest without host payload columns: ids/metadata are derived from the row
+        number on demand (10M-row benchmarks would otherwise hold GBs of Python strings)."""
+        if self._cols["id"]:
+            raise ValueError("shard already holds payload columns")
+        self._main.add_dense(dense)
+        if sparse_csr is not None and "sparse_index" in self.collections:
+            self._main.add_sparse(*sparse_csr)
+        self._synthetic_rows += dense.shape[0]
+
+    def finalize(self):
+        for coll in {id(c.handle): c for c in self.collections.values()}.values():
+            coll.flush()
+
+    # ------------------------------------------------------------------ search
+    @staticmethod
+    def _as_sparse_payload(emb):
+        if isinstance(emb, dict):
+            idx = np.asarray(emb.get("indices", []), dtype=np.int32)
+            val = np.asarray(emb.get("values", []), dtype=np.float32)
+        elif hasattr(emb, "tocsr"):  # scipy sparse matrix (1, dim)
+            m = emb.tocsr()
+            idx, val = m.indices.astype(np.int32), m.data.astype(np.float32)
+        else:
+            raise ValueError("Sparse query embedding must be dict with indices/values or a scipy.sparse matrix")
+        if idx.shape != val.shape:
+            raise ValueError("sparse indices/values length mismatch")
+        order = np.argsort(idx, kind="stable")
+        return idx[order], val[order]
+
+    def _format_hits(self, ids: np.ndarray, scores: np.ndarray) -> List[Dict[str, Any]]:
+        c = self._cols
+        out = []
+        for row, score in zip(ids.tolist(), scores.tolist()):
+            if row < 0:
+                break
+            if self._synthetic_rows:
+                out.append({"id": self.synthetic_id(row), "content": "", "score": float(score),
+                            "metadata": {"doc_id": f"doc{row // 10}", "chunk_index": row % 10, "entropy": 0.0,
+                                         "redundancy": 0.0, "domain_density": 0.0, "timestamp": ""},
+                            "_row": row})
+                continue
+            out.append({"id": c["id"][row], "content": c["content"][row], "score": float(score),
+                        "metadata": {"doc_id": c["doc_id"][row], "chunk_index": c["chunk_index"][row],
+                                     "entropy": c["entropy"][row], "redundancy": c["redundancy"][row],
+                                     "domain_density": c["domain_density"][row], "timestamp": c["timestamp"][row]},
+                        "_row": row})
+        return out
+
+    def _search_blocking(self, query_embedding, collection_name: str, top_k: int, filters: Optional[str],
+                         search_params: Optional[Dict]) -> List[Dict[str, Any]]:
+        coll = self.collections[collection_name]
+        mask = self._row_mask(filters)
+        params = search_params or ({"metric_type": "IP"} if coll.kind == "sparse"
+                                   else {"metric_type": "COSINE", "params": {"ef": 64}})
+        metric = params.get("metric_type", coll.metric)
+        if metric != coll.metric:
+            raise ValueError(f"metric_type {metric} does not match collection {collection_name} ({coll.metric})")
+        if coll.kind == "sparse":
+            idx, val = self._as_sparse_payload(query_embedding)
+            drop = float((params.get("params") or {}).get("drop_ratio_search", 0.0))
+            ids, sc = coll.handle.search_sparse([(idx, val)], top_k, drop, mask)
+        else:
+            q = np.asarray(query_embedding, dtype=np.float32).reshape(1, -1)
+            ids, sc = coll.handle.search_dense(q, top_k, mask)
+        return self._format_hits(ids[0], sc[0])
+
+    async def search(self, query_embedding, collection_name: str, top_k: int = 20, filters: Optional[str] = None,
+                     search_params: Optional[Dict] = None) -> List[Dict[str, Any]]:
+        if collection_name not in self.collections:
+            raise ValueError(f"Collection {collection_name} not found")
+        try:
+            return await asyncio.wait_for(
+                asyncio.to_thread(self._search_blocking, query_embedding, collection_name, top_k, filters,
+                                  search_params),
+                timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)
+        except asyncio.TimeoutError:
+            logging.error("shard search timeout for collection %s", collection_name)
+            raise Exception(f"Search timeout for collection {collection_name}")
+
+    def fuse_rank_lists(self, row_lists: Sequence[Sequence[int]], id_lists: Sequence[Sequence[Any]],
+                        weights: Sequence[float], rrf_k: int = 60):
+        """RRF on the device (csrc/fuse.h) over row numbers; returns
+        [(id, float64 score, [list indices])] in fused order."""
+        if self._main is None:
+            raise RuntimeError("no shard handle")
+        row_to_id = {}
+        for rows, ids in zip(row_lists, id_lists):
+            for r, i in zip(rows, ids):
+                row_to_id.setdefault(int(r), i)
+        lists = [np.asarray(r, dtype=np.int64) for r in row_lists] + [np.zeros(0, np.int64)] * (3 - len(row_lists))
+        w = list(weights) + [0.0] * (3 - len(weights))
+        rows, scores, methods = self._main.fuse_rrf(lists[0], lists[1], lists[2], w[0], w[1], w[2], rrf_k)
+        return [(row_to_id[int(r)], float(s), [b for b in range(3) if (int(m) >> b) & 1])
+                for r, s, m in zip(rows, scores, methods)]
+
+    # ------------------------------------------------------------------ embeddings
+    async def _run_encoder(self, fn, *args):
+        if asyncio.iscoroutinefunction(fn):
+            return await fn(*args)
+        return await asyncio.get_event_loop().run_in_executor(self.embedding_executor, lambda: fn(*args))
+
+    async def _generate_semantic_embeddings_batch(self, texts: List[str]) -> List[np.ndarray]:
+        cache = get_semantic_cache()
+        out: List[Optional[np.ndarray]] = []
+        missing: List[int] = []
+        for i, t in enumerate(texts):
+            hit = await cache.get(t)
+            out.append(hit)
+            if hit is None:
+                missing.append(i)
+        if missing and self.embedding_generator:
+            gen = self.embedding_generator
+            batch_fn = getattr(gen, "encode_semantic_batch", None)
+            miss_texts = [texts[i] for i in missing]
+            if batch_fn is not None:   # one batched forward instead of the reference's per-text loop (:584-587)
+                vecs = await self._run_encoder(batch_fn, miss_texts)
+            elif asyncio.iscoroutinefunction(gen.encode_semantic):
+                vecs = [await gen.encode_semantic(t) for t in miss_texts]
+            else:
+                vecs = await asyncio.get_event_loop().run_in_executor(
+                    self.embedding_executor, lambda: [gen.encode_semantic(t) for t in miss_texts])
+            for i, v in zip(missing, vecs):
+                await cache.put(texts[i], v)
+                out[i] = v
+        else:
+            for i in missing:  # placeholder, uncached in the batch path as in the reference (:593-597)
+                out[i] = np.random.randn(self.semantic_dim).astype(np.float32)
+        return out  # type: ignore[return-value]
+
+    async def _generate_semantic_embedding(self, text: str) -> np.ndarray:
+        async def compute() -> np.ndarray:
+            if self.embedding_generator:
+                return await self._run_encoder(self.embedding_generator.encode_semantic, text)
+            return np.random.randn(self.semantic_dim).astype(np.float32)
+        return await get_semantic_cache().get_or_compute(text, compute)
+
+    async def _generate_sparse_embedding(self, text: str, role: str = "query"):
+        gen = self.embedding_generator
+        if gen:
+            fn = gen.encode_sparse
+            if role == "query" and hasattr(gen, "encode_sparse_query"):
+                fn = gen.encode_sparse_query
+            return await self._run_encoder(fn, text)
+        nnz = min(100, self.sparse_dim)
+        picks = np.random.choice(self.sparse_dim, size=nnz, replace=False)
+        vals = np.abs(np.random.randn(nnz).astype(np.float32))
+        order = np.argsort(picks)
+        return {"indices": picks[order].tolist(), "values": vals[order].astype(float).tolist()}
+
+    async def _generate_domain_embedding(self, text: str, domain: Optional[str] = None) -> np.ndarray:
+        gen = self.embedding_generator
+        if gen:
+            if asyncio.iscoroutinefunction(gen.encode_domain):
+                return await gen.encode_domain(text, domain or "")
+            return await asyncio.get_event_loop().run_in_executor(self.embedding_executor,
+                                                                  lambda: gen.encode_domain(text, domain))
+        return np.random.randn(self.domain_dim).astype(np.float32)
+
+    # ------------------------------------------------------------------ misc
+    def get_collection_stats(self, collection_name: str) -> Dict[str, Any]:
+        coll = self.collections.get(collection_name)
+        if coll is None:
+            return {}
+        return {"name": collection_name, "num_entities": coll.num_entities, "schema": coll.schema,
+                "indexes": coll.indexes}
+
+    async def delete_by_filter(self, collection_name: str, expr: str):
+        if collection_name in self.collections:
+            self.collections[collection_name].delete(expr)
+
+    async def close(self):
+        for h in (self._main, self._domain):
+            if h is not None:
+                try:
+                    h.close()
+                except Exception:
+                    pass
+        self._main = self._domain = None
+        self.collections.clear()
+        if hasattr(self, "embedding_executor"):
+            self.embedding_executor.shutdown(wait=True)
+
+
+HbmIndexManager = MilvusIndexManager

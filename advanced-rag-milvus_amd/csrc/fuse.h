@@ -138,15 +138,16 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(
 // (score desc, id asc); ids < 0 are padding.  One block per query.
 __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict__ scores,
                                                          const int64_t* __restrict__ ids, int n_lists,
+                                                         int64_t score_stride, int64_t id_stride,
                                                          int B, int k_in, int k_out,
                                                          int64_t* __restrict__ out_ids,
                                                          float* __restrict__ out_scores) {
     const int q = blockIdx.x, tid = threadIdx.x;
     const int n = n_lists * k_in;
     auto at = [&](int e, float& s, int64_t& i) {
-        const int64_t o = ((int64_t)(e / k_in) * B + q) * k_in + (e % k_in);
-        s = scores[o];
-        i = ids[o];
+        const int64_t o = (int64_t)q * k_in + (e % k_in);
+        s = scores[(int64_t)(e / k_in) * score_stride + o];
+        i = ids[(int64_t)(e / k_in) * id_stride + o];
     };
     int n_valid = 0;
     for (int e = tid; e < n; e += 256) {
@@ -174,6 +175,46 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const float* __restrict
     for (int i = (n_valid < k_out ? n_valid : k_out) + tid; i < k_out; i += 256) {
         out_ids[(int64_t)q * k_out + i] = -1;
         out_scores[(int64_t)q * k_out + i] = 0.f;
+    }
+}
+
+// Linear re-scorer of LearnedRanker.score (reference ranker.py:109-125):
+//   new = base_w*score + method_bonus*len(retrieval_methods) + recency_w*recency
+// in float64, then HybridRetriever.rerank's stable descending sort and cut
+// (retrieval.py:556-563).  One block per query; entries [B][k_in], n[B] valid.
+__global__ __launch_bounds__(256) void rerank_linear_kernel(
+    const int64_t* __restrict__ ids, const double* __restrict__ scores, const int32_t* __restrict__ methods,
+    const int32_t* __restrict__ n_valid, const double* __restrict__ recency, int k_in, double base_w,
+    double method_bonus, double recency_w, int k_out, int64_t* __restrict__ out_ids,
+    double* __restrict__ out_scores, double* __restrict__ out_orig) {
+    __shared__ double ns[HR_MAX_TOPK];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = min(n_valid[q], k_in);
+    for (int e = tid; e < n; e += 256) {
+        const int64_t o = (int64_t)q * k_in + e;
+        const double mc = (double)__popc((unsigned)methods[o]);
+        const double rec = recency ? recency[o] : 0.0;
+        double v = __dmul_rn(base_w, scores[o]);
+        v = __dadd_rn(v, __dmul_rn(method_bonus, mc));
+        v = __dadd_rn(v, __dmul_rn(recency_w, rec));
+        ns[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < n; e += 256) {
+        const double v = ns[e];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (ns[j] > v) || (ns[j] == v && j < e);
+        if (rank < k_out) {
+            const int64_t o = (int64_t)q * k_in + e;
+            out_ids[(int64_t)q * k_out + rank] = ids[o];
+            out_scores[(int64_t)q * k_out + rank] = v;
+            out_orig[(int64_t)q * k_out + rank] = scores[o];
+        }
+    }
+    for (int i = (n < k_out ? n : k_out) + tid; i < k_out; i += 256) {
+        out_ids[(int64_t)q * k_out + i] = -1;
+        out_scores[(int64_t)q * k_out + i] = 0.0;
+        out_orig[(int64_t)q * k_out + i] = 0.0;
     }
 }
 

@@ -812,14 +812,31 @@ int hr_fuse_rrf_dev(const int64_t* d_ids_a, int ka, const int64_t* d_ids_b, int 
     return HR_OK;
 }
 
-int hr_merge_topk_dev(const float* d_scores, const int64_t* d_ids, int n_lists, int B, int k_in, int k_out,
-                      int64_t* d_out_ids, float* d_out_scores, void* stream) {
+int hr_merge_topk_dev(const float* d_scores, const int64_t* d_ids, int n_lists, int64_t score_stride, int64_t id_stride,
+                      int B, int k_in, int k_out, int64_t* d_out_ids, float* d_out_scores, void* stream) {
     if (n_lists <= 0 || B <= 0 || k_in <= 0 || k_out <= 0) return fail(nullptr, HR_EINVAL, "bad merge sizes");
+    if (score_stride < (int64_t)B * k_in || id_stride < (int64_t)B * k_in)
+        return fail(nullptr, HR_EINVAL, "list stride smaller than one list");
     if (!d_scores || !d_ids || !d_out_ids || !d_out_scores) return fail(nullptr, HR_EINVAL, "null buffer");
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, d_scores, d_ids, n_lists, B, k_in,
-                       k_out, d_out_ids, d_out_scores);
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, d_scores, d_ids, n_lists,
+                       score_stride, id_stride, B, k_in, k_out, d_out_ids, d_out_scores);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, HR_EHIP, "merge_topk_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_rerank_linear_dev(const int64_t* d_ids, const double* d_scores, const int32_t* d_methods, const int32_t* d_n,
+                         const double* d_recency, int B, int k_in, double base_w, double method_bonus,
+                         double recency_w, int k_out, int64_t* d_out_ids, double* d_out_scores, double* d_out_orig,
+                         void* stream) {
+    if (B <= 0 || k_in <= 0 || k_out <= 0) return fail(nullptr, HR_EINVAL, "bad rerank sizes");
+    if (k_in > HR_MAX_TOPK) return fail(nullptr, HR_ELIMIT, "k_in exceeds HR_MAX_TOPK=%d", HR_MAX_TOPK);
+    if (!d_ids || !d_scores || !d_methods || !d_n || !d_out_ids || !d_out_scores || !d_out_orig)
+        return fail(nullptr, HR_EINVAL, "null buffer");
+    hipLaunchKernelGGL(rerank_linear_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, d_ids, d_scores, d_methods, d_n,
+                       d_recency, k_in, base_w, method_bonus, recency_w, k_out, d_out_ids, d_out_scores, d_out_orig);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "rerank_linear_kernel: %s", hipGetErrorString(e));
     return HR_OK;
 }
 

@@ -1,0 +1,341 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/s (+ p50 retrieve() latency) of the hybrid search
+hot path — dense top-k' + sparse top-k' + RRF + learned-ranker rerank — on
+BASELINE.json's metric shape: 10M x 768 fp16 corpus, top_k=20 (k'=40), COSINE,
+sparse docs of 100 nnz over 10k dims, batch of 64 concurrent queries per step.
+
+    python bench.py --gpus N --steps K --warmup W        (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU; the corpus is row-sharded over the N ranks (strong
+scaling: 10M rows in total whatever N), each step ends with one RCCL all-gather
+of the per-shard top-k' lists.  Rank 0 prints ONE JSON line.
+
+What is inside the timed region: K full steps (all kernels + collective) with
+queries already resident in HBM; nothing is cached between steps (each step
+uses a different query batch) and nothing is skipped.  The dense-scan kernel is
+bracketed with HIP events on its own stream inside the timed region
+(hr_set_profiling(1)) to get roofline.achieved.  The CPU baseline (N=1 only) is
+the oracle's numpy/scipy restatement of the reference path timed on a 1M-row
+subsample and extrapolated per row — labelled as such.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "advanced-rag-milvus_amd"))
+sys.path.insert(0, ROOT)
+
+SPARSE_DIM = 10000
+SPARSE_NNZ = 100
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def dense_block(block: int, n: int, dim: int, seed: int = 1234) -> np.ndarray:
+    """Rows of corpus block `block`: N(0,1) fp32 from default_rng(seed + block)."""
+    return np.random.default_rng(seed + block).standard_normal((n, dim), dtype=np.float32)
+
+
+def sparse_block(block: int, n: int, seed: int = 5678):
+    """n sparse docs: 100 distinct ascending indices in [0,10000) (one uniform pick per
+    stratum of 100 — the vectorised stand-in for the reference placeholder's
+    choice(10000, 100, replace=False), indexing.py:647-654) with |N(0,1)| fp32 values."""
+    rng = np.random.default_rng(seed + block)
+    idx = (np.arange(SPARSE_NNZ, dtype=np.int32) * (SPARSE_DIM // SPARSE_NNZ))[None, :] + \
+        rng.integers(0, SPARSE_DIM // SPARSE_NNZ, size=(n, SPARSE_NNZ), dtype=np.int32)
+    val = np.abs(rng.standard_normal((n, SPARSE_NNZ), dtype=np.float32))
+    indptr = np.arange(n + 1, dtype=np.int64) * SPARSE_NNZ
+    return indptr, idx.reshape(-1), val.reshape(-1)
+
+
+def make_queries(n_batches: int, B: int, dim: int, seed: int = 4321):
+    rng = np.random.default_rng(seed)
+    Q = rng.standard_normal((n_batches, B, dim), dtype=np.float32)
+    sq = []
+    for _ in range(n_batches):
+        _, idx, val = sparse_block(0, B, seed=int(rng.integers(1 << 30)))
+        sq.append([(idx[i * SPARSE_NNZ:(i + 1) * SPARSE_NNZ], val[i * SPARSE_NNZ:(i + 1) * SPARSE_NNZ]) for i in range(B)])
+    return Q, sq
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--top-k", type=int, default=20)
+    ap.add_argument("--block-rows", type=int, default=250_000)
+    ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline / parity-gate subsample")
+    ap.add_argument("--latency-queries", type=int, default=200)
+    ap.add_argument("--no-sparse", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--profile-all", action="store_true", help="bracket every kernel phase, not just the scans")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from advanced_rag import _native as nat
+    from advanced_rag.engine import EngineConfig, HybridSearchEngine, pack_sparse_queries, shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    use_sparse = not args.no_sparse
+    N, D, B, blk = args.rows, args.dim, args.batch, min(args.block_rows, args.rows)
+    lo, hi = shard_range(N, rank, world, align=blk)
+    n_local = hi - lo
+    h = nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE, SPARSE_DIM if use_sparse else 0, local_rank)
+    h.set_row_offset(lo)
+    h.reserve(max(n_local, 64))
+
+    # ---- build this rank's shard (generated in blocks by a thread pool, ingested in order) ----------
+    do_cpu = (world == 1 and not args.no_cpu_baseline)
+    cpu_rows = min(args.cpu_rows, N)
+    sample_dense, sample_sparse = [], []
+    t0 = time.time()
+    blocks = [(b, min(blk, N - b * blk)) for b in range(lo // blk, -(-hi // blk))] if n_local else []
+    workers = max(1, min(12, (os.cpu_count() or 8) // max(1, min(world, 8) if world > 1 else 1)))
+
+    def gen(bn):
+        b, n = bn
+        return b, dense_block(b, n, D), (sparse_block(b, n) if use_sparse else None)
+
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        pending = []
+        it = iter(blocks)
+        for _ in range(workers):
+            nxt = next(it, None)
+            if nxt is not None:
+                pending.append(pool.submit(gen, nxt))
+        while pending:
+            b, Xb, Sb = pending.pop(0).result()
+            nxt = next(it, None)
+            if nxt is not None:
+                pending.append(pool.submit(gen, nxt))
+            h.add_dense(Xb)  # fp32 -> fp16 (RNE) on the device
+            if use_sparse:
+                h.add_sparse(*Sb)
+            if do_cpu and b * blk < cpu_rows:
+                take = min(Xb.shape[0], cpu_rows - b * blk)
+                sample_dense.append(Xb[:take].astype(np.float16))
+                if use_sparse:
+                    sample_sparse.append((Sb[1][:take * SPARSE_NNZ], Sb[2][:take * SPARSE_NNZ]))
+            del Xb, Sb
+    h.finalize()
+    torch.cuda.synchronize()
+    log(f"shard rows [{lo},{hi}) built in {time.time() - t0:.1f}s, {h.device_bytes / 1e9:.2f} GB in HBM")
+
+    # ---- queries (resident in HBM before the timed region) --------------------------------------------
+    n_batches = 8
+    Q, SQ = make_queries(n_batches, B, D)
+    cfg = EngineConfig(top_k=args.top_k, use_sparse=use_sparse)
+    eng = HybridSearchEngine(h, cfg, device=str(dev))
+    dQ = [torch.from_numpy(Q[i]).to(dev) for i in range(n_batches)]
+    dS = [eng.upload_sparse(pack_sparse_queries(SQ[i], 0.2)) if use_sparse else None for i in range(n_batches)]
+    kp = 2 * args.top_k
+
+    # ---- parity gate on the CPU subsample (N=1): GPU restricted by a row mask vs the canonical oracle -----
+    parity = None
+    if do_cpu:
+        import oracle
+        Xs = np.concatenate(sample_dense)
+        n_s = Xs.shape[0]
+        mask = np.zeros((n_local + 7) // 8, dtype=np.uint8)
+        mask[: n_s // 8] = 0xFF
+        for r in range(n_s // 8 * 8, n_s):
+            mask[r >> 3] |= 1 << (r & 7)
+        n_gate = 4
+        gids, gsc = h.search_dense(Q[0][:n_gate], kp, mask)
+        oids, osc = oracle.dense_search(Xs, Q[0][:n_gate], kp, oracle.COSINE)
+        ok = bool(np.array_equal(gids, oids) and np.array_equal(gsc.view(np.uint32), osc.view(np.uint32)))
+        fused_ok = True
+        if use_sparse:
+            s_idx = np.concatenate([p[0] for p in sample_sparse])
+            s_val = np.concatenate([p[1] for p in sample_sparse])
+            s_ptr = np.arange(n_s + 1, dtype=np.int64) * SPARSE_NNZ
+            sids, ssc = h.search_sparse(SQ[0][:n_gate], kp, 0.2, mask)
+            osids, ossc = oracle.sparse_search(s_ptr, s_idx, s_val, SQ[0][:n_gate], kp, 0.2)
+            ok = ok and bool(np.array_equal(sids, osids) and np.array_equal(ssc.view(np.uint32), ossc.view(np.uint32)))
+            for i in range(n_gate):
+                fi, fs, _ = h.fuse_rrf(gids[i], sids[i][sids[i] >= 0], (), cfg.dense_weight, cfg.sparse_weight, 0.2, 60)
+                oi, os_, _ = oracle.rrf(oids[i], osids[i][osids[i] >= 0], (), cfg.dense_weight, cfg.sparse_weight, 0.2, 60)
+                fused_ok = fused_ok and bool(np.array_equal(fi, oi) and np.max(np.abs(fs - os_), initial=0.0) <= 1e-4)
+        parity = {"sample_rows": int(n_s), "queries": n_gate, "ids_bit_exact": ok, "fused_within_1e-4": fused_ok}
+        log(f"parity gate on {n_s} rows: {parity}")
+        if not (ok and fused_ok):
+            print(json.dumps({"error": "parity gate failed", "parity": parity}))
+            sys.exit(2)
+
+    # ---- timed region -----------------------------------------------------------------------------------
+    def step(i):
+        return eng.search(dQ[i % n_batches], dS[i % n_batches])
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    h.kernel_ms()  # drop warm-up spans
+    h.set_profiling(2 if args.profile_all else 1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    h.set_profiling(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    phases = h.kernel_ms()
+    flags_exact = bool(out["flags"].min().item() == 1)
+    if world > 1:
+        ft = torch.tensor([1 if flags_exact else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ft, op=dist.ReduceOp.MIN)
+        flags_exact = bool(ft.item())
+
+    scan_ms, scan_launches = phases["dense_scan"]
+    scan_bytes = h.dense_scan_bytes
+    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+
+    # ---- p50 latency of single-query retrieve() through the Python API (N=1) --------------------------------
+    latency = None
+    if world == 1 and not args.no_latency and args.latency_queries > 0:
+        latency = measure_latency(h, Q, SQ, args, use_sparse)
+
+    # ---- CPU baseline (N=1): the reference path with Milvus replaced by numpy/scipy, on the subsample -----------
+    cpu = None
+    if do_cpu:
+        import scipy.sparse as sp
+        import oracle
+        X32 = Xs.astype(np.float32)
+        X32 /= np.maximum(np.linalg.norm(X32, axis=1, keepdims=True), 1e-30)
+        csr = q_csr = None
+        if use_sparse:
+            csr = sp.csr_matrix((s_val, s_idx, s_ptr), shape=(n_s, SPARSE_DIM), dtype=np.float32)
+            p, i_, v_, _ = pack_sparse_queries(SQ[1], 0.2)
+            q_csr = sp.csr_matrix((v_, i_, p), shape=(B, SPARSE_DIM), dtype=np.float32)
+        oracle.cpu_hybrid(X32, csr, Q[1][:4], q_csr[:4] if use_sparse else None, args.top_k) if use_sparse else \
+            oracle.cpu_dense_topk(X32, Q[1][:4], kp)  # warm-up
+        reps, t_cpu = 0, 0.0
+        while t_cpu < 10.0 and reps < 20:
+            t1 = time.perf_counter()
+            if use_sparse:
+                oracle.cpu_hybrid(X32, csr, Q[1], q_csr, args.top_k)
+            else:
+                oracle.cpu_dense_topk(X32, Q[1], kp)
+            t_cpu += time.perf_counter() - t1
+            reps += 1
+        per_batch = t_cpu / reps * (N / n_s)  # per-row extrapolation to the full corpus
+        cpu = {"value": B / per_batch, "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+               "sample": f"oracle.cpu_hybrid (numpy fp32 BLAS matmul + argpartition, scipy CSR*q, Python RRF) on the "
+                         f"first {n_s} rows x {B} queries, {reps} reps, time extrapolated x{N / n_s:.1f} to {N} rows"}
+
+    if rank == 0:
+        total_q = B * args.steps
+        res = {
+            "metric": "queries_per_sec_hybrid_retrieve", "value": total_q / elapsed, "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{N}x{D} fp16 COSINE corpus" + (f" + sparse {SPARSE_NNZ}nnz/{SPARSE_DIM}d" if use_sparse else "")
+                       + f", hybrid dense+sparse k'={kp} -> RRF(k=60, 0.7/0.3) top_k={args.top_k} -> learned-ranker rerank "
+                       f"{args.top_k}->{cfg.rerank_top_k}, batch {B} queries/step (BASELINE config 4 without the cross-encoder forward)",
+                       "rows": N, "dim": D, "batch": B, "top_k": args.top_k, "k_prime": kp,
+                       "parallelism": f"row-sharded x{world}, one RCCL all-gather of per-shard top-k' per step" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "dense_scan_kernel<f16>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches},
+            "cpu_baseline": cpu,
+            "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
+            "all_lists_proven_exact": flags_exact,
+        }
+        if latency:
+            res.update(latency)
+        if parity:
+            res["parity_gate"] = parity
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def measure_latency(h, Q, SQ, args, use_sparse):
+    """p50/p95 wall time of `await HybridRetriever.retrieve(query, profile_hint="default")` for single
+    queries: host buffers in, Python dicts out (string ids), both searches + device RRF."""
+    import asyncio
+    from advanced_rag.constants import RetrievalConstants
+    from advanced_rag.indexing import MilvusIndexManager
+    from advanced_rag.retrieval import HybridRetriever, RetrievalConfig
+
+    mgr = MilvusIndexManager(semantic_dim=args.dim, sparse_dim=SPARSE_DIM, connect=False)
+    mgr._connect()
+    from advanced_rag.indexing import ShardCollection
+    mgr._main = h
+    mgr.collections["semantic_index"] = ShardCollection(mgr, "semantic_index", "dense", h, args.dim, "COSINE")
+    if use_sparse:
+        mgr.collections["sparse_index"] = ShardCollection(mgr, "sparse_index", "sparse", h, SPARSE_DIM, "IP")
+    mgr._synthetic_rows = h.num_rows
+    flatQ = Q.reshape(-1, args.dim)
+    flatS = [s for batch in SQ for s in batch]
+
+    class Gen:
+        def encode_semantic(self, text):
+            return flatQ[int(text[1:])]
+
+        def encode_sparse(self, text):
+            qi, qv = flatS[int(text[1:])]
+            return {"indices": qi.tolist(), "values": qv.tolist()}
+
+        def encode_domain(self, text, domain=None):
+            return np.zeros(768, np.float32)
+
+    mgr.embedding_generator = Gen()
+    RetrievalConstants.TIMEOUT_SECONDS = 60.0
+    retr = HybridRetriever(mgr, RetrievalConfig(top_k=args.top_k))
+    n = min(args.latency_queries, flatQ.shape[0])
+
+    async def run():
+        lat = []
+        for i in range(n + 10):
+            t0 = time.perf_counter()
+            out = await retr.retrieve(f"q{i % flatQ.shape[0]}", profile_hint="default")
+            dt = (time.perf_counter() - t0) * 1e3
+            assert len(out) == args.top_k
+            if i >= 10:
+                lat.append(dt)
+        return lat
+
+    lat = asyncio.run(run())
+    mgr.embedding_executor.shutdown(wait=False)
+    return {"p50_retrieve_ms": float(np.percentile(lat, 50)), "p95_retrieve_ms": float(np.percentile(lat, 95)),
+            "latency_queries": n}
+
+
+if __name__ == "__main__":
+    main()

@@ -159,11 +159,24 @@ HR_API int hr_fuse_rrf_dev(const int64_t* d_ids_a, int ka, const int64_t* d_ids_
                     int rrf_k, int top_k, int64_t* d_out_ids, double* d_out_scores,
                     int32_t* d_out_methods, int32_t* d_n_out, void* stream);
 /* Cross-shard merge after the RCCL all-gather: n_lists per-shard lists of
- * k_in (score, id) pairs per query, layout [n_lists][B][k_in]; output the
+ * k_in (score, id) pairs per query; list l starts l*score_stride floats /
+ * l*id_stride int64s after the base pointers and is laid out [B][k_in] (so the
+ * lists can sit inside the ranks' slots of one all-gather buffer); output the
  * best k_out by (score desc, id asc).  (No reference analogue: Milvus merges
  * its num_shards=4 segments server-side, indexing.py:234-239.) */
-HR_API int hr_merge_topk_dev(const float* d_scores, const int64_t* d_ids, int n_lists, int B, int k_in,
-                      int k_out, int64_t* d_out_ids, float* d_out_scores, void* stream);
+HR_API int hr_merge_topk_dev(const float* d_scores, const int64_t* d_ids, int n_lists, int64_t score_stride,
+                      int64_t id_stride, int B, int k_in, int k_out, int64_t* d_out_ids,
+                      float* d_out_scores, void* stream);
+/* LearnedRanker.score + HybridRetriever.rerank's stable sort and cut
+ * (reference ranker.py:109-125, retrieval.py:544-563) for a batch:
+ *   new = base_w*score + method_bonus*popcount(methods) + recency_w*recency
+ * Inputs are the outputs of hr_fuse_rrf_dev ([B][k_in], d_n[B] valid entries);
+ * d_recency may be NULL (= 0).  Outputs [B][k_out]: ids, new scores, and the
+ * fused score each kept entry had before (original_retrieval_score). */
+HR_API int hr_rerank_linear_dev(const int64_t* d_ids, const double* d_scores, const int32_t* d_methods,
+                         const int32_t* d_n, const double* d_recency, int B, int k_in, double base_w,
+                         double method_bonus, double recency_w, int k_out, int64_t* d_out_ids,
+                         double* d_out_scores, double* d_out_orig, void* stream);
 
 /* ---- measurement hooks -------------------------------------------------------
  * hr_set_profiling(1) brackets every dense-scan and sparse-scan launch with

@@ -1,0 +1,145 @@
+"""Sparse TAAT + RRF + cross-shard merge parity (HIP through the C ABI vs the oracle)."""
+import numpy as np
+import pytest
+
+import oracle
+from advanced_rag import _native as nat
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def make_sparse(rng, n, V, nnz):
+    """Reference placeholder shape (indexing.py:647-654): nnz distinct indices, |N(0,1)| values, sorted."""
+    indptr = np.arange(n + 1, dtype=np.int64) * nnz
+    idx = np.empty(n * nnz, dtype=np.int32)
+    for r in range(n):
+        idx[r * nnz:(r + 1) * nnz] = np.sort(rng.choice(V, size=nnz, replace=False))
+    val = np.abs(rng.standard_normal(n * nnz)).astype(np.float32)
+    return indptr, idx, val
+
+
+def make_queries(rng, B, V, nnz):
+    out = []
+    for _ in range(B):
+        qi = np.sort(rng.choice(V, size=nnz, replace=False)).astype(np.int32)
+        out.append((qi, np.abs(rng.standard_normal(nnz)).astype(np.float32)))
+    return out
+
+
+@pytest.mark.parametrize("n,V,nnz,B,k,drop", [(500, 1000, 20, 3, 10, 0.0), (5000, 10000, 100, 8, 40, 0.2),
+                                               (9000, 2000, 30, 17, 40, 0.2), (70, 50, 5, 4, 100, 0.5)])
+def test_sparse_matches_oracle(gpu, n, V, nnz, B, k, drop):
+    rng = np.random.default_rng(n + V)
+    indptr, idx, val = make_sparse(rng, n, V, nnz)
+    queries = make_queries(rng, B, V, min(nnz, V))
+    h = nat.ShardHandle(0, sparse_dim=V)
+    half = n // 2
+    h.add_sparse(indptr[:half + 1], idx, val)  # two ragged CSR batches
+    h.add_sparse(indptr[half:], idx, val)
+    h.finalize()
+    assert h.num_sparse_rows == n
+    ids, sc = h.search_sparse(queries, k, drop)
+    oids, osc = oracle.sparse_search(indptr, idx, val, queries, k, drop)
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(_bits(sc), _bits(osc))
+    h.close()
+
+
+def test_sparse_edge_cases(gpu):
+    rng = np.random.default_rng(11)
+    V = 300
+    # ragged rows incl. empty ones, an empty query, a query with no match
+    rows = [np.sort(rng.choice(V - 10, size=s, replace=False)).astype(np.int32) for s in (0, 1, 5, 0, 40, 3, 0, 12)]
+    indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    idx = np.concatenate(rows).astype(np.int32)
+    val = np.abs(rng.standard_normal(len(idx))).astype(np.float32)
+    queries = [(np.zeros(0, np.int32), np.zeros(0, np.float32)),
+               (np.array([V - 1, V - 2], np.int32), np.ones(2, np.float32)),
+               (rows[4][:7], np.abs(rng.standard_normal(7)).astype(np.float32))]
+    h = nat.ShardHandle(0, sparse_dim=V)
+    h.add_sparse(indptr, idx, val)
+    h.finalize()
+    ids, sc = h.search_sparse(queries, 5, 0.0)
+    oids, osc = oracle.sparse_search(indptr, idx, val, queries, 5, 0.0)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sc), _bits(osc))
+    assert (ids[0] == -1).all() and (ids[1] == -1).all()
+    # row mask
+    allow = np.array([1, 1, 0, 1, 0, 1, 1, 1], dtype=bool)
+    mask = np.packbits(allow, bitorder="little")
+    ids, sc = h.search_sparse(queries, 5, 0.0, mask)
+    oids, osc = oracle.sparse_search(indptr, idx, val, queries, 5, 0.0, mask)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sc), _bits(osc))
+    with pytest.raises(ValueError):
+        h.add_sparse(np.array([0, 2], np.int64), np.array([5, 5], np.int32), np.ones(2, np.float32))  # not ascending
+    with pytest.raises(ValueError):
+        h.add_sparse(np.array([0, 1], np.int64), np.array([V], np.int32), np.ones(1, np.float32))  # out of range
+    h.close()
+
+
+@pytest.mark.parametrize("na,nb,nc,overlap", [(5, 3, 0, True), (40, 40, 0, True), (40, 40, 20, True), (0, 7, 0, False),
+                                               (6, 0, 0, False), (80, 80, 0, True), (1, 1, 1, True)])
+def test_rrf_matches_oracle(gpu, na, nb, nc, overlap):
+    rng = np.random.default_rng(na * 100 + nb)
+    pool = rng.permutation(10 * (na + nb + nc + 1)).astype(np.int64)
+    a = pool[:na]
+    b = np.concatenate([a[::3], pool[na:]])[:nb] if overlap else pool[na:na + nb]
+    b = rng.permutation(b)
+    c = rng.permutation(np.concatenate([a[1::4], b[::2], pool[-nc:]]))[:nc] if nc else np.zeros(0, np.int64)
+    _, uniq = np.unique(c, return_index=True)
+    c = c[np.sort(uniq)]
+    h = nat.ShardHandle(8)
+    for wa, wb, wc in ((0.7, 0.3, 0.2), (0.5, 0.5, 0.5), (1.0, 0.0, 0.2)):
+        gi, gs, gm = h.fuse_rrf(a, b, c, wa, wb, wc, 60)
+        oi, os_, om = oracle.rrf(a, b, c, wa, wb, wc, 60)
+        assert np.array_equal(gi, oi)
+        assert np.array_equal(gs.view(np.uint64), os_.view(np.uint64))  # float64, bit for bit
+        assert np.array_equal(gm, om)
+    h.close()
+
+
+def test_merge_topk_and_batched_rrf_dev(gpu):
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    G, B, k = 4, 6, 40
+    scores = rng.standard_normal((G, B, k)).astype(np.float32)
+    scores[:, :, ::5] = 0.25  # ties across shards
+    scores = -np.sort(-scores, axis=2)
+    ids = rng.permutation(G * B * k).reshape(G, B, k).astype(np.int64)
+    ids[1, :, 30:] = -1  # a short shard
+    ts, ti = torch.from_numpy(scores).to(dev), torch.from_numpy(ids).to(dev)
+    oi = torch.empty((B, k), dtype=torch.int64, device=dev)
+    os_ = torch.empty((B, k), dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nat.merge_topk_dev(ts.data_ptr(), ti.data_ptr(), G, B, k, k, oi.data_ptr(), os_.data_ptr(), st)
+    torch.cuda.synchronize()
+    for b in range(B):
+        flat_s, flat_i = scores[:, b, :].ravel(), ids[:, b, :].ravel()
+        keep = flat_i >= 0
+        order = np.lexsort((flat_i[keep], -flat_s[keep]))[:k]
+        assert np.array_equal(oi[b].cpu().numpy(), flat_i[keep][order])
+        assert np.array_equal(os_[b].cpu().numpy(), flat_s[keep][order])
+    # batched RRF on device
+    a = np.stack([rng.permutation(1000)[:40] for _ in range(B)]).astype(np.int64)
+    bb = np.stack([np.concatenate([a[i, ::2], 2000 + rng.permutation(100)[:20]]) for i in range(B)]).astype(np.int64)
+    bb[2, 25:] = -1
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(bb).to(dev)
+    top_k = 20
+    fo = torch.empty((B, top_k), dtype=torch.int64, device=dev)
+    fs = torch.empty((B, top_k), dtype=torch.float64, device=dev)
+    fm = torch.empty((B, top_k), dtype=torch.int32, device=dev)
+    fn = torch.empty((B,), dtype=torch.int32, device=dev)
+    nat.fuse_rrf_dev(ta.data_ptr(), 40, tb.data_ptr(), 40, 0, 0, B, 0.7, 0.3, 0.2, 60, top_k, fo.data_ptr(),
+                     fs.data_ptr(), fm.data_ptr(), fn.data_ptr(), st)
+    torch.cuda.synchronize()
+    for i in range(B):
+        oi_, os2, om = oracle.rrf(a[i], bb[i], (), 0.7, 0.3, 0.2, 60)
+        n = min(top_k, len(oi_))
+        assert int(fn[i]) == n
+        assert np.array_equal(fo[i, :n].cpu().numpy(), oi_[:n])
+        assert np.array_equal(fs[i, :n].cpu().numpy().view(np.uint64), os2[:n].view(np.uint64))
+        assert np.array_equal(fm[i, :n].cpu().numpy(), om[:n])

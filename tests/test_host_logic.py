@@ -1,0 +1,402 @@
+"""Host-side logic of the product package against the reference's golden outputs; the
+test bodies mirror the reference's own tests (test_extended.py:81-426, :533-548,
+tests/test_embedding_cache.py, test_advanced_rag.py:287-300) with asyncio.run in place
+of pytest-asyncio."""
+import asyncio
+import json
+import os
+
+import numpy as np
+import pytest
+
+from advanced_rag import (AdvancedRAGPipeline, HybridRetriever, LearnedRanker, MilvusIndexManager, PipelineConfig,
+                          PipelineStage, RetrievalConfig, CrossEncoderReranker, QueryClassifier, BM25SparseEncoder)
+from advanced_rag.chunking import chunk_id_for
+from advanced_rag.constants import RetrievalConstants
+from advanced_rag.embedding_cache import EmbeddingCache, get_domain_cache, get_semantic_cache, get_sparse_cache
+from advanced_rag.query_rewriting import QueryRewriter
+from advanced_rag import filters
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def hits(ids, prefix):
+    return [{"id": i, "content": f"{prefix} {i}", "score": 1.0 - 0.01 * r} for r, i in enumerate(ids)]
+
+
+def test_fuse_results_matches_reference_bit_for_bit():
+    for c in gold("g1_fuse.json"):
+        r = HybridRetriever(index_manager=None,
+                            config=RetrievalConfig(dense_weight=c["dense_weight"], sparse_weight=c["sparse_weight"]))
+        out = r._fuse_results(hits(c["semantic"], "s"), hits(c["sparse"], "p"), hits(c["domain"], "d"))
+        assert [o["id"] for o in out] == c["ids"], c["label"]
+        assert [float(o["score"]).hex() for o in out] == c["scores"], c["label"]
+        assert [sorted(o["retrieval_methods"]) for o in out] == c["methods"]
+        assert [o["content"].split()[0] for o in out] == c["payload_from"]  # which list supplied the payload
+
+
+def test_rerank_paths_match_reference():
+    g = {c["label"]: c for c in gold("g2_rerank.json")}
+    c = g["learned-ranker"]
+    r = HybridRetriever(index_manager=None, config=RetrievalConfig(enable_learned_ranker=True), learned_ranker=LearnedRanker())
+    out = asyncio.run(r.rerank("q", r._fuse_results(hits(c["semantic"], "s"), hits(c["sparse"], "p"), []), top_k=c["top_k"]))
+    assert [o["id"] for o in out] == c["ids"]
+    assert [float(o["score"]).hex() for o in out] == c["scores"]
+    assert [float(o["original_retrieval_score"]).hex() for o in out] == c["original"]
+
+    class Inject:
+        async def score(self, pairs):
+            return list(g["injected-stable"]["inject"])
+
+    r = HybridRetriever(index_manager=None)
+    r.reranker = Inject()
+    res = [{"id": x, "content": x, "score": 0.5 - 0.1 * i} for i, x in enumerate("ABCD")]
+    out = asyncio.run(r.rerank("q", res, top_k=None))
+    assert [o["id"] for o in out] == g["injected-stable"]["ids"] and len(out) == g["injected-stable"]["n"]
+    r = HybridRetriever(index_manager=None, config=RetrievalConfig(enable_reranking=False))
+    res = [{"id": x, "content": x, "score": 0.5} for x in "ABC"]
+    assert [o["id"] for o in asyncio.run(r.rerank("q", list(res), top_k=2))] == g["disabled"]["top2"]
+    assert [o["id"] for o in asyncio.run(r.rerank("q", list(res)))] == g["disabled"]["none"]
+
+
+def test_rerank_placeholder_and_external_scores():  # reference test_extended.py:238-273
+    r = HybridRetriever(index_manager=None)
+    res = [{"id": "A", "content": "alpha", "score": 0.5}, {"id": "B", "content": "bravo", "score": 0.4},
+           {"id": "C", "content": "charlie", "score": 0.3}]
+    out = asyncio.run(r.rerank(query="q", results=res, top_k=2))
+    assert len(out) == 2 and "rerank_score" in out[0]
+
+    class Flip:
+        async def score(self, pairs):
+            return [0.1, 0.9]
+
+    r.reranker = Flip()
+    out = asyncio.run(r.rerank("q", [{"id": "A", "content": "a", "score": 0.5}, {"id": "B", "content": "b", "score": 0.4}], 2))
+    assert [x["id"] for x in out] == ["B", "A"]
+    assert len(asyncio.run(CrossEncoderReranker().score([("q", "d")] * 3))) == 3
+
+
+def test_classifier_profiles_and_defaults_match_reference():
+    g = gold("g3_profiles.json")
+    clf = QueryClassifier()
+    for q, want in g["classify"]:
+        assert clf.classify(q) == want, q
+    for key, profs in g["profiles"].items():
+        k, rk = map(int, key.split(","))
+        hr = HybridRetriever(index_manager=None, config=RetrievalConfig(top_k=k, rerank_top_k=rk))
+        assert set(hr.profiles) == set(profs)
+        for name, want in profs.items():
+            p = hr.profiles[name]
+            got = {"top_k": p.top_k, "rerank_top_k": p.rerank_top_k, "enable_mmr": p.enable_mmr, "mmr_lambda": p.mmr_lambda,
+                   "enable_reranking": p.enable_reranking, "dense_weight": p.dense_weight, "sparse_weight": p.sparse_weight}
+            assert got == want, (key, name)
+    assert RetrievalConstants.MAX_TOP_K == g["max_top_k"] and RetrievalConstants.TIMEOUT_SECONDS == g["timeout_seconds"]
+    cfg = RetrievalConfig()
+    for field, want in g["default_config"].items():
+        assert getattr(cfg, field) == want, field
+
+
+def test_filter_expressions_match_reference():
+    hr = HybridRetriever(index_manager=None)
+    for c in gold("g4_filters.json"):
+        if "error" in c:
+            with pytest.raises(Exception) as ei:
+                hr._build_filter_expression(c["filters"])
+            assert type(ei.value).__name__ == c["error"], c
+        else:
+            assert hr._build_filter_expression(c["filters"]) == c["expr"], c
+
+
+def test_filter_expression_evaluates_to_row_mask():
+    cols = {"doc_id": np.array(["a", 'q"x', "a\\b", "z"]), "entropy": np.array([0.1, 0.5, 0.9, 0.3], np.float32),
+            "chunk_index": np.array([0, 1, 2, 3]), "timestamp": np.array(["2023-05-01", "2024-02-01", "2024-12-31", "2025-01-01"])}
+    hr = HybridRetriever(index_manager=None)
+    expr = hr._build_filter_expression({"doc_id": 'q"x', "entropy": {"$gte": 0.2}})
+    assert filters.evaluate(expr, cols, 4).tolist() == [False, True, False, False]
+    expr = hr._build_filter_expression({"doc_id": "a\\b"})
+    assert filters.evaluate(expr, cols, 4).tolist() == [False, False, True, False]
+    expr = hr._build_filter_expression({"timestamp": {"$gte": "2024-01-01", "$lt": "2025-01-01"}, "chunk_index": {"$ne": 2}})
+    assert filters.evaluate(expr, cols, 4).tolist() == [False, True, False, False]
+    assert filters.pack(np.array([1, 0, 1, 1, 0, 0, 0, 0, 1], bool)).tolist() == [0b00001101, 0b1]
+    with pytest.raises(ValueError):
+        filters.evaluate('entropy >= "x"', cols, 4)
+    with pytest.raises(ValueError):
+        filters.evaluate("nosuch == 1", cols, 4)
+    assert filters.parse('doc_id == "a and b" and chunk_index == 3') == [("doc_id", "==", "a and b"), ("chunk_index", "==", 3)]
+
+
+def test_mmr_diversification():  # reference test_extended.py:189-213
+    cfg = RetrievalConfig(hybrid_alpha=0.7, top_k=3, enable_mmr=True, mmr_lambda=0.6)
+    r = HybridRetriever(index_manager=None, config=cfg)
+    sem = [{"id": "A", "content": "alpha alpha content one", "score": 0.95}, {"id": "B", "content": "bravo content two", "score": 0.85},
+           {"id": "C", "content": "alpha content three", "score": 0.80}]
+    sp = [{"id": "A", "content": "alpha alpha content one", "score": 0.75}, {"id": "D", "content": "delta unique different", "score": 0.70},
+          {"id": "E", "content": "echo also different", "score": 0.65}]
+    fused = r._fuse_results(semantic_results=sem, sparse_results=sp, domain_results=[])
+    assert len(fused) <= 3 and fused[0]["id"] == "A"
+    assert {"D", "E", "C", "B"} & {x["id"] for x in fused}
+
+
+class FakeIndexManager:
+    def __init__(self, with_meta=True, delay=0.0):
+        self.with_meta, self.delay, self.calls = with_meta, delay, []
+
+    async def _generate_semantic_embedding(self, text):
+        if self.delay:
+            await asyncio.sleep(self.delay)
+        return np.ones(4, dtype=np.float32)
+
+    async def _generate_sparse_embedding(self, text):
+        return np.zeros(4, dtype=np.float32)
+
+    async def _generate_domain_embedding(self, text, domain):
+        return np.full(4, 2.0, dtype=np.float32)
+
+    async def search(self, query_embedding, collection_name, top_k=20, filters=None, search_params=None):
+        self.calls.append((collection_name, top_k, filters))
+        tag = {"semantic_index": "S", "sparse_index": "P", "domain_index": "D"}[collection_name]
+        hit = {"id": tag, "content": tag.lower(), "score": 0.9}
+        if self.with_meta:
+            hit["metadata"] = {"doc_id": "d" + tag}
+        return [hit]
+
+
+def test_retrieve_with_domain_profile_tagging_and_k_prime():  # reference test_extended.py:276-331 + SURVEY App. A
+    mgr = FakeIndexManager()
+    r = HybridRetriever(index_manager=mgr)
+    out = asyncio.run(r.retrieve(query="What is RAG?", filters={"doc_id": "x"}, use_domain_index=True, domain="tech"))
+    assert {o["id"] for o in out} == {"S", "P", "D"}
+    assert all(o["metadata"]["retrieval_profile"] == "faq" for o in out)
+    assert ("semantic_index", 20, 'doc_id == "x"') in mgr.calls and ("domain_index", 10, 'doc_id == "x"') in mgr.calls
+    mgr.calls.clear()
+    asyncio.run(r.retrieve(query="What is RAG?", profile_hint="default"))
+    assert mgr.calls[0][1] == 40  # 2 * top_k over-retrieval
+    r2 = HybridRetriever(index_manager=FakeIndexManager(with_meta=False))
+    out = asyncio.run(r2.retrieve(query="What is RAG?"))
+    assert out and "retrieval_profile" in out[0]
+
+
+def test_retrieve_timeout_and_weight_adapter():  # reference test_extended.py:334-388
+    r = HybridRetriever(index_manager=FakeIndexManager(delay=0.02))
+    old = RetrievalConstants.TIMEOUT_SECONDS
+    RetrievalConstants.TIMEOUT_SECONDS = 0.005
+    try:
+        assert asyncio.run(r.retrieve(query="slow query")) == []
+    finally:
+        RetrievalConstants.TIMEOUT_SECONDS = old
+    r = HybridRetriever(index_manager=FakeIndexManager(), weight_adapter=lambda q: (1.5, -0.2))
+    assert (r.config.dense_weight, r.config.sparse_weight) == (0.7, 0.3)
+    asyncio.run(r.retrieve(query="q"))
+    assert (r.config.dense_weight, r.config.sparse_weight) == (1.0, 0.0)
+
+
+def test_sparse_skipped_when_collection_missing_and_search_errors_degrade():
+    class M(FakeIndexManager):
+        collections = {"semantic_index": 1}
+    mgr = M()
+    asyncio.run(HybridRetriever(index_manager=mgr).retrieve("q"))
+    assert [c[0] for c in mgr.calls] == ["semantic_index"]
+
+    class Broken(FakeIndexManager):
+        async def search(self, *a, **k):
+            raise RuntimeError("boom")
+    assert asyncio.run(HybridRetriever(index_manager=Broken()).retrieve("q")) == []
+
+
+def test_retrieve_end_to_end_matches_reference_on_config1():
+    """BASELINE config 1 (1k x 384, dense-only and hybrid): this package's HybridRetriever over a numpy
+    FLAT manager reproduces the reference's ids, fused scores and method tags (golden g5)."""
+    g = gold("g5_retrieve_c1.json")
+    N, D = g["N"], g["D"]
+    X = np.random.default_rng(g["corpus_seed"]).standard_normal((N, D)).astype(np.float32)
+    Xn = X / np.linalg.norm(X, axis=1, keepdims=True)
+    srng = np.random.default_rng(g["sparse_seed"])
+    rows = []
+    for _ in range(N):
+        idx = np.arange(100) * 100 + srng.integers(0, 100, size=100)
+        rows.append((idx.astype(np.int32), np.abs(srng.standard_normal(100)).astype(np.float32)))
+    qrng = np.random.default_rng(g["query_seed"])
+    Q = qrng.standard_normal((g["n_queries"], D)).astype(np.float32)
+    SQ = [((np.arange(100) * 100 + qrng.integers(0, 100, size=100)).astype(np.int32),
+           np.abs(qrng.standard_normal(100)).astype(np.float32)) for _ in range(g["n_queries"])]
+
+    class NumpyManager:
+        def __init__(self, with_sparse):
+            self.collections = {"semantic_index": 1, **({"sparse_index": 1} if with_sparse else {})}
+            self.q = None
+
+        async def _generate_semantic_embedding(self, text):
+            return self.q[0]
+
+        async def _generate_sparse_embedding(self, text):
+            return {"indices": self.q[1][0].tolist(), "values": self.q[1][1].tolist()}
+
+        async def search(self, query_embedding, collection_name, top_k=20, filters=None, search_params=None):
+            if collection_name == "semantic_index":
+                s = Xn @ (query_embedding / np.linalg.norm(query_embedding))
+            else:
+                idx, val = np.asarray(query_embedding["indices"]), np.asarray(query_embedding["values"], np.float32)
+                keep = np.sort(np.argsort(np.abs(val), kind="stable")[int(np.floor(0.2 * len(val))):])
+                qd = np.zeros(10000)
+                qd[idx[keep]] = val[keep]
+                s = np.array([float(np.sum(qd[ri] * rv.astype(np.float64))) for ri, rv in rows], dtype=np.float32)
+            order = [int(i) for i in np.lexsort((np.arange(len(s)), -s))[:top_k] if collection_name == "semantic_index" or s[i] > 0]
+            return [{"id": f"doc{r // 10}::{r % 10}::{r:08x}", "content": f"row {r}", "score": float(s[r]),
+                     "metadata": {"doc_id": f"doc{r // 10}", "chunk_index": r % 10}} for r in order]
+
+    old = RetrievalConstants.TIMEOUT_SECONDS
+    RetrievalConstants.TIMEOUT_SECONDS = 60.0
+    try:
+        for run in g["runs"]:
+            mgr = NumpyManager(run["with_sparse"])
+            mgr.q = (Q[run["query"]], SQ[run["query"]])
+            out = asyncio.run(HybridRetriever(mgr, RetrievalConfig(top_k=20)).retrieve("plain statement", profile_hint="default"))
+            assert [o["id"] for o in out] == run["ids"]
+            assert [float(o["score"]).hex() for o in out] == run["scores"]
+            assert [sorted(o["retrieval_methods"]) for o in out] == run["methods"]
+            assert out[0]["metadata"]["retrieval_profile"] == run["profile"]
+    finally:
+        RetrievalConstants.TIMEOUT_SECONDS = old
+
+
+def test_embedding_cache_trace_matches_reference():
+    g = gold("g7_cache.json")
+    cache = EmbeddingCache(max_size=g["max_size"], ttl_seconds=3600)
+    for op, key, want in g["trace"]:
+        if op == "put":
+            cache._sync_put(key, np.full(2, ord(key), dtype=np.float32))
+        else:
+            v = cache._sync_get(key)
+            assert (None if v is None else float(v[0])) == want, (op, key)
+    st = cache.get_stats()
+    for k, want in g["stats"].items():
+        assert st[k] == want, k
+    assert cache._materialize_key("a") == g["key_a"] and cache._materialize_key("text", "model") == g["key_text_model"]
+
+
+def test_embedding_cache_api_sync_async_ttl_and_singletons():  # reference tests/test_embedding_cache.py
+    c = EmbeddingCache(maxsize=2, ttl_seconds=1)
+    assert c.max_size == c.maxsize == 2
+    asyncio.run(_cache_roundtrip(c))
+    c2 = EmbeddingCache(max_size=4, ttl_seconds=1)
+    c2._sync_put("k", np.ones(1))
+    c2._cache[c2._materialize_key("k")] = (0.0, np.ones(1))  # force expiry
+    assert c2._sync_get("k") is None and c2.get_stats()["size"] == 0
+    off = EmbeddingCache(enabled=False)
+    off._sync_put("k", 1)
+    assert off._sync_get("k") is None
+    assert get_semantic_cache() is get_semantic_cache() and get_sparse_cache().max_size == 10000
+    assert get_domain_cache().max_size == 5000
+    c.clear()
+    assert c.get_stats()["hits"] == 0 and c.get_stats()["size"] == 0
+
+
+async def _cache_roundtrip(c):
+    assert await c.get("x") is None
+    await c.put("x", np.arange(3))
+    assert (await c.get("x")).tolist() == [0, 1, 2]
+    await c.put("text", "model", np.ones(2))
+    assert (await c.get("text", "model")).tolist() == [1, 1]
+    calls = []
+
+    async def compute():
+        calls.append(1)
+        return np.full(2, 7.0)
+
+    assert (await c.get_or_compute("y", compute))[0] == 7.0
+    assert (await c.get_or_compute("y", compute))[0] == 7.0 and len(calls) == 1
+    assert c.get_stats()["evictions"] >= 1
+
+
+def test_chunk_ids_and_query_rewriting_match_reference():
+    for c in gold("g8_chunk_ids.json"):
+        assert chunk_id_for(c["doc_id"], c["index"], c["content"]) == c["chunk_id"]
+    qr = QueryRewriter()
+    for q, want in gold("g10_rewrite.json"):
+        assert qr.rewrite(q, {}) == want
+
+
+def test_learned_ranker_monotone_and_feedback():  # reference test_extended.py:533-548, :694-713
+    lr = LearnedRanker()
+    res = [{"id": "a", "score": 0.2, "retrieval_methods": ["semantic", "sparse"]}, {"id": "b", "score": 0.2, "retrieval_methods": ["semantic"]},
+           {"id": "c", "score": 0.1}]
+    s = asyncio.run(lr.score("q", res))
+    assert s[0] > s[1] > s[2] and s[0] == 0.2 + 0.1 * 2
+    lr.update_from_feedback("q", res, [{"id": "a", "label": 1.0}, {"id": "zzz", "label": 0.0}])
+    assert len(lr.training_examples) == 1 and lr.training_examples[0].label == 1.0
+
+
+def test_manager_and_pipeline_without_connect():  # reference test_extended.py:391-426, :798-805, :849-859, :957-961
+    m = MilvusIndexManager(connect=False)
+    assert m.collections == {} and (m.semantic_dim, m.sparse_dim, m.domain_dim, m.num_shards) == (1536, 10000, 768, 4)
+    sem = asyncio.run(m._generate_semantic_embedding("hello"))
+    assert sem.shape == (1536,) and sem.dtype == np.float32
+    sp = asyncio.run(m._generate_sparse_embedding("hello"))
+    assert len(sp["indices"]) == 100 and sp["indices"] == sorted(sp["indices"]) and min(sp["values"]) >= 0
+    assert asyncio.run(m._generate_domain_embedding("x", "d")).shape == (768,)
+    with pytest.raises(ValueError):
+        asyncio.run(m.search(np.zeros(4), "semantic_index"))
+    assert m.get_collection_stats("semantic_index") == {}
+
+    class Gen:
+        async def encode_semantic(self, t):
+            return np.full(4, 1.0, np.float32)
+
+        def encode_sparse(self, t):
+            return np.arange(4, dtype=np.float32)
+
+        async def encode_domain(self, t, d=""):
+            return np.full(4, 2.0, np.float32)
+
+    m2 = MilvusIndexManager(semantic_dim=4, sparse_dim=4, domain_dim=4, connect=False)
+    m2.embedding_generator = Gen()
+    assert np.all(asyncio.run(m2._generate_semantic_embedding("unique-text-1")) == 1.0)
+    assert np.all(asyncio.run(m2._generate_sparse_embedding("x")) == np.arange(4))
+    assert np.all(asyncio.run(m2._generate_domain_embedding("x", domain="d")) == 2.0)
+    asyncio.run(m.close())
+    asyncio.run(m2.close())
+
+    p = AdvancedRAGPipeline(connect_to_milvus=False, config=PipelineConfig(enable_audit_logging=False))
+    assert p.config.top_k == 20 and p.config.rerank_top_k == 5 and p.retriever.config.rerank_top_k == 5
+    assert p.retriever.config.dense_weight == 0.7 and p.retriever.learned_ranker is not None
+    for ms in (10.0, 20.0, 100.0):
+        p._record_latency(PipelineStage.RETRIEVAL, ms)
+    rep = p.get_performance_report()
+    assert rep["stage_latencies"]["retrieval"]["p50"] == 20.0 and 0 < rep["sla_compliance"]["compliance_rate"] < 1
+    asyncio.run(p.close())
+
+
+def test_pipeline_retrieve_shape_with_fake_manager():
+    p = AdvancedRAGPipeline(connect_to_milvus=False, config=PipelineConfig(enable_audit_logging=True))
+    p.index_manager = FakeIndexManager()
+    p.retriever.index_manager = p.index_manager
+    p.retriever.config.enable_learned_ranker = True
+    results, metrics = asyncio.run(p.retrieve("plain statement", context={"retrieval_profile": "default"}))
+    assert results and results[0].chunk_id in {"S", "P"} and results[0].audit_trail is not None
+    assert 0.0 <= metrics.hallucination_risk <= 1.0 and set(metrics.to_dict()) >= {"retrieval_precision", "ndcg_at_k"}
+    plan = asyncio.run(p.plan_and_execute("alpha and beta"))
+    assert plan["decomposition"]["sub_queries"] == ["alpha", "beta"] and len(plan["subqueries"]) == 2
+
+
+def test_bm25_encoder_scores_equal_textbook_bm25():
+    docs = ["the quick brown fox jumps", "the lazy dog sleeps all day long", "quick quick fox", "unrelated text entirely"]
+    enc = BM25SparseEncoder(sparse_dim=4096).fit(docs)
+    q = enc.encode_query("quick fox")
+    scores = []
+    for d in docs:
+        dv = enc.encode_document(d)
+        dd = dict(zip(dv["indices"], dv["values"]))
+        scores.append(sum(v * dd.get(i, 0.0) for i, v in zip(q["indices"], q["values"])))
+    assert scores[2] > scores[0] > 0 and scores[1] == 0 and scores[3] == 0
+    import math
+    toks = "quick quick fox".split()
+    idf = lambda df: math.log(1 + (4 - df + 0.5) / (df + 0.5))
+    avgdl = sum(len(d.split()) for d in docs) / 4
+    want = sum(idf(2) * tf * 2.2 / (tf + 1.2 * (1 - 0.75 + 0.75 * 3 / avgdl)) for tf in (2, 1))
+    assert abs(scores[2] - want) < 1e-5
+    assert q["indices"] == sorted(q["indices"])

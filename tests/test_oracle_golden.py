@@ -1,0 +1,112 @@
+"""The oracle against the reference's own outputs (tests/golden/*.json, generated from the
+imported reference by tests/golden/gen_golden.py) and against itself (C vs numpy)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return json.load(f)
+
+
+def _intern(*lists):
+    table = {}
+    out = []
+    for lst in lists:
+        out.append([table.setdefault(x, len(table)) for x in lst])
+    return out, {v: k for k, v in table.items()}
+
+
+@pytest.mark.parametrize("impl", [oracle.rrf, oracle.rrf_py])
+def test_rrf_matches_reference_fuse_results(impl):
+    cases = gold("g1_fuse.json")
+    assert len(cases) >= 20
+    for c in cases:
+        (a, b, d), back = _intern(c["semantic"], c["sparse"], c["domain"])
+        ids, scores, methods = impl(a, b, d, c["dense_weight"], c["sparse_weight"], 0.2, 60)
+        assert [back[int(i)] for i in ids] == c["ids"], c["label"]
+        assert [float(s).hex() for s in scores] == c["scores"], c["label"]  # float64, bit for bit
+        names = ("semantic", "sparse", "domain")
+        assert [sorted(n for bit, n in enumerate(names) if (int(m) >> bit) & 1) for m in methods] == c["methods"]
+
+
+def test_rrf_known_values_from_survey():
+    ids, scores, _ = oracle.rrf([0, 1, 2, 3, 4], [3, 7, 0])
+    assert ids.tolist() == [0, 3, 1, 2, 4, 7]
+    assert scores[0] == 0.016237314597970336 and scores[1] == 0.015855532786885247
+    assert 0.7 / 61 == 0.011475409836065573
+
+
+def test_dense_c_and_numpy_agree_bit_for_bit():
+    rng = np.random.default_rng(0)
+    for dt in (np.float16, np.float32):
+        X = rng.standard_normal((777, 130)).astype(np.float32).astype(dt)
+        X[5] = 0
+        q = rng.standard_normal(130).astype(np.float32)
+        for metric in (oracle.IP, oracle.COSINE):
+            a, b = oracle.dense_scores(X, q, metric), oracle.dense_scores_np(X, q, metric)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert oracle.dense_scores(X, q, oracle.COSINE)[5] == 0.0
+        assert np.all(oracle.dense_scores(X, np.zeros(130, np.float32), oracle.COSINE) == 0.0)
+
+
+def test_dense_close_to_fp32_blas_path():
+    """Canonical scores vs the numpy fp32 'reference path' (BASELINE.md §3): within 1e-4, same ids when gaps allow."""
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((5000, 384)).astype(np.float32)
+    Q = rng.standard_normal((4, 384)).astype(np.float32)
+    Xn = X / np.linalg.norm(X, axis=1, keepdims=True)
+    ids, sc = oracle.cpu_dense_topk(Xn, Q, 40)
+    oids, osc = oracle.dense_search(X, Q, 40, oracle.COSINE)
+    assert np.max(np.abs(sc - osc)) < 1e-4
+    assert np.array_equal(ids, oids)
+
+
+def test_topk_tie_rule_mask_and_padding():
+    s = np.array([0.5, 0.9, 0.5, 0.9, -1.0, 0.0], dtype=np.float32)
+    ids, sc = oracle.topk(s, 4)
+    assert ids.tolist() == [1, 3, 0, 2]
+    ids, _ = oracle.topk(s, 8, only_positive=True)
+    assert ids.tolist() == [1, 3, 0, 2, -1, -1, -1, -1]
+    mask = np.packbits(np.array([1, 0, 1, 1, 1, 1], bool), bitorder="little")
+    ids, _ = oracle.topk(s, 3, mask, row_offset=100)
+    assert ids.tolist() == [103, 100, 102]
+
+
+def test_drop_query_semantics():
+    i, v = oracle.drop_query([5, 1, 9, 3, 7], [0.5, 0.1, 0.3, 0.1, 0.9], 0.4)
+    assert i.tolist() == [5, 7, 9] and np.allclose(v, [0.5, 0.9, 0.3])
+    i, v = oracle.drop_query([4, 2], [1.0, 1.0], 0.5)  # equal magnitudes: the later entry goes first
+    assert i.tolist() == [4]
+    i, v = oracle.drop_query([], [], 0.2)
+    assert len(i) == 0
+
+
+def test_sparse_scores_vs_scipy():
+    sp = pytest.importorskip("scipy.sparse")
+    rng = np.random.default_rng(2)
+    n, V, nnz = 400, 300, 12
+    idx = np.stack([np.sort(rng.choice(V, nnz, replace=False)) for _ in range(n)]).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * nnz)).astype(np.float32)
+    ptr = np.arange(n + 1, dtype=np.int64) * nnz
+    qi = np.sort(rng.choice(V, 20, replace=False)).astype(np.int32)
+    qv = np.abs(rng.standard_normal(20)).astype(np.float32)
+    got = oracle.sparse_scores(ptr, idx, val, qi, qv)
+    qd = np.zeros(V, np.float64)
+    qd[qi] = qv
+    want = sp.csr_matrix((val.astype(np.float64), idx, ptr), shape=(n, V)) @ qd
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+
+
+def test_half_conversion_is_numpy_astype():
+    rng = np.random.default_rng(3)
+    v = (rng.standard_normal(4000) * 10.0 ** rng.integers(-9, 6, 4000)).astype(np.float32)
+    v[:6] = [0.0, -0.0, 65504.0, 65520.0, 1e-8, 6.1e-5]
+    assert np.array_equal(oracle.float_to_half_bits(v), v.astype(np.float16).view(np.uint16))
