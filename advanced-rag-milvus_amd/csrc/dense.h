@@ -65,12 +65,17 @@ __global__ void prep_queries_kernel(const float* __restrict__ q, int B, int dim,
     const int slot = blockIdx.x;
     const int g = slot >> 4, col = slot & 15;
     __shared__ float s_inv;
+    __shared__ float s_q[HR_MAX_DIM];
+    if (slot < B)
+        for (int k = threadIdx.x; k < dim; k += blockDim.x) s_q[k] = q[(int64_t)slot * dim + k];
+    __syncthreads();
     if (threadIdx.x == 0) {
+        // canonical |q|^2: k-ordered fp64 sum (the oracle does the same); the
+        // operands come from LDS so only the add chain is serial
         double s = 0.0;
         if (slot < B) {
-            const float* qq = q + (int64_t)slot * dim;
             for (int k = 0; k < dim; ++k) {
-                double x = (double)qq[k];
+                double x = (double)s_q[k];
                 s = __dadd_rn(s, __dmul_rn(x, x));
             }
             qn2[slot] = s;
@@ -84,7 +89,7 @@ __global__ void prep_queries_kernel(const float* __restrict__ q, int B, int dim,
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
             int k = kc * EPC + j;
-            float x = (slot < B && k < dim) ? q[(int64_t)slot * dim + k] * inv : 0.0f;
+            float x = (slot < B && k < dim) ? s_q[k] * inv : 0.0f;
             out.e[j] = (STORE)x;
         }
         int kt = kc >> 2, c = kc & 3;

@@ -57,12 +57,12 @@ enum Phase { PH_PREP = 0, PH_SCAN, PH_GSEL, PH_REFINE, PH_TOPK, PH_SSCAN, PH_SGS
 
 struct Workspace {
     hipStream_t stream = nullptr;  // own stream (host-form calls)
-    DevBuf qfrag, qn2, gmax, cand, acut, cscore, crow, flags;
+    DevBuf qfrag, qn2, gmax, bmax, cand, acut, cscore, crow, flags, qscale, qeps;
     DevBuf d_q, d_ids, d_scores, d_mask;          // host-form staging
     DevBuf d_qptr, d_qidx, d_qval;                // sparse query staging
     DevBuf f_ids, f_out_ids, f_out_scores, f_out_meth, f_n;  // hr_fuse_rrf staging
     void release() {
-        for (DevBuf* b : {&qfrag, &qn2, &gmax, &cand, &acut, &cscore, &crow, &flags, &d_q, &d_ids, &d_scores,
+        for (DevBuf* b : {&qfrag, &qn2, &gmax, &bmax, &qscale, &qeps, &cand, &acut, &cscore, &crow, &flags, &d_q, &d_ids, &d_scores,
                           &d_mask, &d_qptr, &d_qidx, &d_qval, &f_ids, &f_out_ids, &f_out_scores, &f_out_meth, &f_n})
             b->release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -96,6 +96,7 @@ struct hr_index {
     std::vector<int32_t> h_idx;
     std::vector<float> h_val;
     int64_t n_sparse = 0, n_sparse_built = -1;
+    float max_sparse_abs = 0.f;  // max |doc weight|: bounds the scan's fixed-point range
     DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post_doc, post_val;
     int64_t n_ranges = 0;
 
@@ -266,6 +267,30 @@ int max_groups_for_dim(const hr_index* h) {
     return std::max(1, std::min(4, g));
 }
 
+// Two-level candidate selection: per-bucket maxima, then one block per query.
+int launch_group_select(hr_index* h, Workspace* ws, hipStream_t s, int B, int64_t n_groups, int C) {
+    const int64_t n_buckets = (n_groups + kBucketGroups - 1) / kBucketGroups;
+    HIP_TRY(h, ws->bmax.ensure((size_t)B * n_buckets * sizeof(float)));
+    if (n_groups > C && n_buckets > C) {
+        hipLaunchKernelGGL(bucket_max_kernel, dim3((unsigned)((n_buckets + 3) / 4), B), dim3(256), 0, s,
+                           ws->gmax.as<float>(), n_groups, n_buckets, ws->bmax.as<float>());
+        HIP_TRY(h, hipGetLastError());
+    }
+    hipLaunchKernelGGL(select_groups_kernel, dim3(B), dim3(1024), 0, s, ws->gmax.as<float>(), ws->bmax.as<float>(),
+                       n_groups, n_buckets, C, ws->cand.as<int32_t>(), ws->acut.as<float>());
+    HIP_TRY(h, hipGetLastError());
+    return HR_OK;
+}
+
+// Escalation ladder of the host forms when a list is not provably exact:
+// default -> 4x (bounded by the selection kernel's bucket table) -> every group.
+constexpr int kMaxSelectGroups = 448;
+int next_candidate_count(int C, int64_t n_groups) {
+    const int64_t all = round_up(n_groups, 16);
+    if (C < kMaxSelectGroups && (int64_t)C * 4 < all) return std::min(C * 4, kMaxSelectGroups);
+    return (int)all;
+}
+
 int candidate_groups_for_k(int k) {
     int c = k + std::max(16, k / 2);
     return (int)round_up(c, 16);
@@ -326,9 +351,7 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     }
     {
         Span sp(h, s, PH_GSEL);
-        hipLaunchKernelGGL(select_groups_kernel, dim3(B), dim3(1024), 0, s, ws->gmax.as<float>(), n_groups, C,
-                           ws->cand.as<int32_t>(), ws->acut.as<float>());
-        HIP_TRY(h, hipGetLastError());
+        HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
     }
     {
         Span sp(h, s, PH_REFINE);
@@ -350,9 +373,10 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
         float eps_abs;
         int norm_mode;
         dense_eps(h, &eps_abs, &norm_mode);
-        hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), 0, s, ws->cscore.as<float>(),
+        hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, s, ws->cscore.as<float>(),
                            ws->crow.as<int32_t>(), C * kGroupRows, k, h->row_offset, ws->acut.as<float>(),
-                           -INFINITY, eps_abs, 0.0f, norm_mode, ws->qn2.as<double>(), d_ids, d_scores, d_flags);
+                           -INFINITY, eps_abs, (const float*)nullptr, 0.0f, norm_mode, ws->qn2.as<double>(), d_ids,
+                           d_scores, d_flags);
         HIP_TRY(h, hipGetLastError());
     }
     return HR_OK;
@@ -367,37 +391,43 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     HIP_TRY(h, ws->acut.ensure((size_t)B * sizeof(float)));
     HIP_TRY(h, ws->cscore.ensure((size_t)B * C * kGroupRows * sizeof(float)));
     HIP_TRY(h, ws->crow.ensure((size_t)B * C * kGroupRows * sizeof(int32_t)));
+    HIP_TRY(h, ws->qscale.ensure((size_t)B * sizeof(float)));
+    HIP_TRY(h, ws->qeps.ensure((size_t)B * sizeof(float)));
     const int64_t V1 = h->sparse_dim + 1;
+    hipLaunchKernelGGL(sparse_query_prep_kernel, dim3(B), dim3(256), 0, s, d_qptr, d_qval, h->max_sparse_abs,
+                       ws->qscale.as<float>(), ws->qeps.as<float>());
+    HIP_TRY(h, hipGetLastError());
     for (int q0 = 0; q0 < B; q0 += 32768) {  // gridDim.y limit
         const int nq = std::min(32768, B - q0);
         Span sp(h, s, PH_SSCAN);
-        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(256), 0, s,
+        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(1024), 0, s,
                            h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(),
-                           h->post_doc.as<uint16_t>(), h->post_val.as<float>(), d_qptr + q0, d_qidx, d_qval, d_mask,
-                           h->n_sparse, n_groups, ws->gmax.as<float>() + (int64_t)q0 * n_groups);
+                           h->post_doc.as<uint16_t>(), h->post_val.as<float>(), d_qptr + q0, d_qidx, d_qval,
+                           ws->qscale.as<float>() + q0, d_mask, h->n_sparse, n_groups,
+                           ws->gmax.as<float>() + (int64_t)q0 * n_groups);
         HIP_TRY(h, hipGetLastError());
     }
     {
         Span sp(h, s, PH_SGSEL);
-        hipLaunchKernelGGL(select_groups_kernel, dim3(B), dim3(1024), 0, s, ws->gmax.as<float>(), n_groups, C,
-                           ws->cand.as<int32_t>(), ws->acut.as<float>());
-        HIP_TRY(h, hipGetLastError());
+        HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
     }
     {
         Span sp(h, s, PH_SREFINE);
-        hipLaunchKernelGGL(refine_sparse_kernel, dim3(C, B), dim3(64), 0, s, h->s_indptr.as<int64_t>(),
+        hipLaunchKernelGGL(refine_sparse_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
                            h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
                            ws->cand.as<int32_t>(), C, h->n_sparse, ws->cscore.as<float>(), ws->crow.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
     }
     {
         Span sp(h, s, PH_STOPK);
-        // fp32 products and fp32 LDS atomic adds in arbitrary order over <= max_q_nnz
-        // non-negative terms: relative error of the scan's sums.
-        const float eps_rel = (float)(2.0 * (max_q_nnz + 2) * std::ldexp(1.0, -24));
-        hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(256), 0, s, ws->cscore.as<float>(),
+        // scan error = fixed-point rounding ((nnz+1)/scale per query, from the prep
+        // kernel) + fp32 rounding of w*scale, of the product and of the int->float
+        // conversion (relative, 2^-22 with margin).
+        (void)max_q_nnz;
+        const float eps_rel = (float)std::ldexp(1.0, -22);
+        hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, s, ws->cscore.as<float>(),
                            ws->crow.as<int32_t>(), C * kGroupRows, k, h->row_offset, ws->acut.as<float>(), 0.0f, 0.0f,
-                           eps_rel, 0, (const double*)nullptr, d_ids, d_scores, d_flags);
+                           ws->qeps.as<float>(), eps_rel, 0, (const double*)nullptr, d_ids, d_scores, d_flags);
         HIP_TRY(h, hipGetLastError());
     }
     return HR_OK;
@@ -694,6 +724,7 @@ int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indices, co
     if (n == 0) return HR_OK;
     const int64_t nnz = indptr[n] - indptr[0];
     if (nnz < 0 || (nnz > 0 && (!indices || !values))) return fail(h, HR_EINVAL, "bad indices/values");
+    float batch_max = 0.f;
     for (int64_t r = 0; r < n; ++r) {
         if (indptr[r + 1] < indptr[r]) return fail(h, HR_EINVAL, "indptr not monotone at row %lld", (long long)r);
         int32_t prev = -1;
@@ -702,6 +733,8 @@ int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indices, co
             if (t < 0 || t >= h->sparse_dim)
                 return fail(h, HR_EINVAL, "sparse index %d out of range [0,%lld) in row %lld", t, (long long)h->sparse_dim, (long long)r);
             if (t <= prev) return fail(h, HR_EINVAL, "sparse indices must be strictly ascending (row %lld)", (long long)r);
+            if (!std::isfinite(values[e])) return fail(h, HR_EINVAL, "non-finite sparse value in row %lld", (long long)r);
+            batch_max = std::max(batch_max, std::fabs(values[e]));
             prev = t;
         }
     }
@@ -717,6 +750,7 @@ int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indices, co
         return fail(h, HR_ENOMEM, "out of host memory staging sparse rows");
     }
     h->n_sparse += n;
+    h->max_sparse_abs = std::max(h->max_sparse_abs, batch_max);
     h->finalized = false;
     return HR_OK;
 }
@@ -878,7 +912,7 @@ int hr_search_dense(hr_index* h, const float* q, int B, int k, const uint8_t* ro
         HIP_TRY(h, hipStreamSynchronize(s));
         const bool all_exact = std::all_of(flags.begin(), flags.end(), [](int32_t f) { return f != 0; });
         if (all_exact || C >= n_groups) break;
-        C = (int)std::min<int64_t>((int64_t)C * 4, round_up(n_groups, 16));  // widen the candidate set and redo
+        C = next_candidate_count(C, n_groups);  // widen the candidate set and redo
     }
     HIP_TRY(h, hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
@@ -967,7 +1001,7 @@ int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx,
         HIP_TRY(h, hipStreamSynchronize(s));
         const bool all_exact = std::all_of(flags.begin(), flags.end(), [](int32_t f) { return f != 0; });
         if (all_exact || C >= n_groups) break;
-        C = (int)std::min<int64_t>((int64_t)C * 4, round_up(n_groups, 16));
+        C = next_candidate_count(C, n_groups);
     }
     HIP_TRY(h, hipMemcpyAsync(out_ids, ws->d_ids.p, (size_t)B * k * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));

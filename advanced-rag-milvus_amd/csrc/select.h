@@ -1,12 +1,16 @@
 // Exact selection kernels: block-wide radix select over unique 64-bit ranking
 // keys (score desc, index asc).  Used twice per modality:
-//   select_groups : top-C candidate groups from the scan's per-group maxima
+//   select_groups : top-C candidate groups from the scan's per-group maxima,
+//                   two-level (buckets of 64 groups first) so a query touches
+//                   ~n_groups/64 + 64*C values instead of n_groups
 //   select_topk   : final top-k rows from the refined (canonical) candidates
 // plus the proof-of-exactness flag that ties the two together.
 #pragma once
 #include "common.h"
 
 namespace hbmrag {
+
+constexpr int kBucketGroups = 64;  // candidate groups per level-2 bucket (4096 rows)
 
 struct SelectScratch {
     unsigned int hist[256];
@@ -17,6 +21,8 @@ struct SelectScratch {
 
 // K-th largest of n keys given by key(i), all threads of the block take part.
 // Keys must be unique except for the invalid key 0.  Requires 1 <= K <= n.
+// 8 passes of 8 bits; the 256-bin suffix scan of each pass is done by wave 0
+// (4 bins per lane + a wave scan) instead of a serial walk.
 template <typename KeyFn>
 __device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, SelectScratch& sh) {
     uint64_t prefix = 0, mask = 0;
@@ -29,15 +35,30 @@ __device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, Select
             if ((kk & mask) == prefix) atomicAdd(&sh.hist[(kk >> shift) & 255], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int cum = 0, d = 255;
-            for (; d > 0; --d) {
-                int c = (int)sh.hist[d];
-                if (cum + c >= remaining) break;
-                cum += c;
+        if (threadIdx.x < 64) {
+            // lane l owns bins 255-4l .. 252-4l (descending), so an inclusive scan over
+            // lanes is the count of keys in all higher bins.
+            const int lane = threadIdx.x;
+            const int top = 255 - 4 * lane;
+            const int c0 = (int)sh.hist[top], c1 = (int)sh.hist[top - 1], c2 = (int)sh.hist[top - 2],
+                      c3 = (int)sh.hist[top - 3];
+            const int mine = c0 + c1 + c2 + c3;
+            int incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                int y = __shfl_up(incl, off);
+                if (lane >= off) incl += y;
             }
-            sh.digit = d;
-            sh.remaining = remaining - cum;
+            const int before = incl - mine;  // keys in bins above this lane's
+            if (before < remaining && incl >= remaining) {  // exactly one lane
+                int cum = before, d = top;
+                if (cum + c0 >= remaining) d = top;
+                else if ((cum += c0) + c1 >= remaining) d = top - 1;
+                else if ((cum += c1) + c2 >= remaining) d = top - 2;
+                else { cum += c2; d = top - 3; }
+                sh.digit = d;
+                sh.remaining = remaining - cum;
+            }
         }
         __syncthreads();
         prefix |= (uint64_t)sh.digit << shift;
@@ -48,34 +69,76 @@ __device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, Select
     return prefix;
 }
 
-// One block per query.  gmax[q][n_groups] -> cand[q][C] (group ids, -1 padded)
-// and a_cut[q]: the largest approximate score any row OUTSIDE the candidate
-// groups can have (-inf when every group is a candidate).
+// Level-2 maxima: one wave per (query, bucket of 64 consecutive groups).
+__global__ __launch_bounds__(256) void bucket_max_kernel(const float* __restrict__ gmax, int64_t n_groups,
+                                                         int64_t n_buckets, float* __restrict__ bmax) {
+    const int q = blockIdx.y;
+    const int64_t bucket = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bucket >= n_buckets) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t g = bucket * kBucketGroups + lane;
+    float v = g < n_groups ? gmax[(int64_t)q * n_groups + g] : -__builtin_inff();
+    v = wave_max(v);
+    if (lane == 0) bmax[(int64_t)q * n_buckets + bucket] = v;
+}
+
+// One block per query.  gmax[q][n_groups] (+ bmax[q][n_buckets]) -> cand[q][C]
+// (group ids, -1 padded) and a_cut[q]: an upper bound on the approximate score
+// of every row OUTSIDE the candidate groups (-inf when every group is a
+// candidate).  Groups outside the selected buckets are bounded by the best
+// unselected bucket maximum, groups inside them by the (C+1)-th candidate key.
 __global__ __launch_bounds__(1024) void select_groups_kernel(const float* __restrict__ gmax,
-                                                             int64_t n_groups, int C,
+                                                             const float* __restrict__ bmax, int64_t n_groups,
+                                                             int64_t n_buckets, int C,
                                                              int32_t* __restrict__ cand,
                                                              float* __restrict__ a_cut) {
     __shared__ SelectScratch sh;
+    __shared__ int32_t sel_bucket[HR_MAX_TOPK * 2];  // C <= k + k/2 rounded to 16 (<= 400)
     const int q = blockIdx.x;
     const float* gm = gmax + (int64_t)q * n_groups;
     int32_t* out = cand + (int64_t)q * C;
+    const float NEG_INF = -__builtin_inff();
     if (n_groups <= C) {
         for (int i = threadIdx.x; i < C; i += blockDim.x) out[i] = (i < n_groups) ? i : -1;
-        if (threadIdx.x == 0) a_cut[q] = -__builtin_inff();
+        if (threadIdx.x == 0) a_cut[q] = NEG_INF;
         return;
     }
-    auto key = [&](int64_t i) { return rank_key(gm[i], (uint32_t)i); };
-    // (C+1)-th largest group max bounds everything that is left out.
-    const uint64_t t_next = block_kth_largest(key, n_groups, C + 1, sh);
-    if (threadIdx.x == 0) {
-        sh.count = 0;
-        a_cut[q] = key_score(t_next);
+    // ---- level 2: the C buckets with the largest maxima
+    float bucket_cut = NEG_INF;
+    int nb;
+    if (n_buckets <= C) {
+        nb = (int)n_buckets;
+        for (int i = threadIdx.x; i < nb; i += blockDim.x) sel_bucket[i] = i;
+    } else {
+        const float* bm = bmax + (int64_t)q * n_buckets;
+        auto bkey = [&](int64_t i) { return rank_key(bm[i], (uint32_t)i); };
+        const uint64_t t_b = block_kth_largest(bkey, n_buckets, C + 1, sh);
+        bucket_cut = key_score(t_b);
+        if (threadIdx.x == 0) sh.count = 0;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n_buckets; i += blockDim.x)
+            if (bkey(i) > t_b) sel_bucket[atomicAdd(&sh.count, 1)] = (int32_t)i;
+        nb = C;
     }
     __syncthreads();
-    for (int64_t i = threadIdx.x; i < n_groups; i += blockDim.x) {
-        if (key(i) > t_next) {
-            int slot = atomicAdd(&sh.count, 1);
-            out[slot] = (int32_t)i;  // exactly C keys are > the (C+1)-th largest
+    // ---- level 1: the C best groups inside those buckets
+    const int64_t n_cand = (int64_t)nb * kBucketGroups;
+    auto gkey = [&](int64_t i) -> uint64_t {
+        const int64_t g = (int64_t)sel_bucket[i >> 6] * kBucketGroups + (i & 63);
+        return g < n_groups ? rank_key(gm[g], (uint32_t)g) : 0ull;  // key 0 = padding, never selected
+    };
+    const uint64_t t_g = block_kth_largest(gkey, n_cand, C + 1, sh);
+    if (threadIdx.x == 0) {
+        sh.count = 0;
+        const float inner = t_g ? key_score(t_g) : NEG_INF;
+        a_cut[q] = fmaxf(inner, bucket_cut);
+    }
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n_cand; i += blockDim.x) {
+        const uint64_t kk = gkey(i);
+        if (kk > t_g) {  // exactly C keys beat the (C+1)-th largest (n_groups > C guarantees C+1 valid keys)
+            const int slot = atomicAdd(&sh.count, 1);
+            if (slot < C) out[slot] = (int32_t)key_row(kk);
         }
     }
 }
@@ -88,10 +151,11 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(const float* __rest
 //   a_cut by more than the scan's error bound.
 // norm_mode: 0 = scores compare to a_cut as they are; 1 = divide by |q| first
 // (inner-product metric: the scan works on the unit-normalised query).
-__global__ __launch_bounds__(256) void select_topk_kernel(
+__global__ __launch_bounds__(1024) void select_topk_kernel(
     const float* __restrict__ cscore, const int32_t* __restrict__ crow, int n, int K,
     int64_t row_offset, const float* __restrict__ a_cut, float cut_floor, float eps_abs,
-    float eps_rel, int norm_mode, const double* __restrict__ qn2, int64_t* __restrict__ out_ids,
+    const float* __restrict__ eps_abs_q, float eps_rel, int norm_mode, const double* __restrict__ qn2,
+    int64_t* __restrict__ out_ids,
     float* __restrict__ out_scores, int32_t* __restrict__ flags) {
     __shared__ SelectScratch sh;
     __shared__ uint64_t sel[HR_MAX_TOPK];
@@ -141,7 +205,8 @@ __global__ __launch_bounds__(256) void select_topk_kernel(
                 double nq = qn2[q];
                 sk = nq > 0.0 ? sk / sqrt(nq) : 0.0;
             }
-            double bound = (double)cut + (double)eps_abs + (double)eps_rel * fabs((double)cut);
+            double bound = (double)cut + (double)eps_abs + (eps_abs_q ? (double)eps_abs_q[q] : 0.0) +
+                           (double)eps_rel * fabs((double)cut);
             exact = sk > bound;
         }
         flags[q] = exact;

@@ -10,8 +10,8 @@
 
 namespace hbmrag {
 
-constexpr int kRangeDocs = 4096;                      // docs per range = LDS accumulator length
-constexpr int kRangeGroups = kRangeDocs / kGroupRows;  // 64 candidate groups per range
+constexpr int kRangeDocs = 16384;                     // docs per range = LDS accumulator length (u16 local ids)
+constexpr int kRangeGroups = kRangeDocs / kGroupRows;  // 256 candidate groups per range
 constexpr int kScanTermChunk = 256;                   // query terms staged per pass
 
 // ---- build: CSR (doc-major) -> range-major postings ---------------------------
@@ -80,105 +80,212 @@ __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int
     }
 }
 
-// ---- scan: grid (n_ranges, B), 256 threads --------------------------------------
-// The block owns docs [range*4096, +4096) of one query: accumulators live in
-// LDS (16 KiB), every posting of the query's terms inside the range is applied
-// with an LDS float atomic, and only the per-64-doc maxima leave the CU.
+// ---- query prep: fixed-point scale per query -------------------------------------
+// The scan accumulates in 32-bit FIXED POINT (LDS integer atomics run ~4x the
+// rate of LDS float atomics on gfx950, and integer sums do not depend on the
+// order the waves arrive in).  With S = sum |w_q| and M = max |doc weight| every
+// partial sum is bounded by S*M, so scale = 2^30/(S*M) cannot overflow int32.
+// Each contribution is rounded AWAY from zero (a positive product always counts
+// at least 1), hence |fixed/scale - exact| <= (nnz+1)/scale: that bound is
+// written to q_eps for the exactness check of select_topk.
+__global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* __restrict__ q_indptr,
+                                                                const float* __restrict__ q_val, float max_doc_w,
+                                                                float* __restrict__ q_scale,
+                                                                float* __restrict__ q_eps) {
+    __shared__ float part[256];
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    const int64_t t0 = q_indptr[qi], t1 = q_indptr[qi + 1];
+    float s = 0.f;
+    for (int64_t i = t0 + tid; i < t1; i += 256) s += fabsf(q_val[i]);
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {  // fixed tree: the same value in every launch
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float bound = part[0] * max_doc_w;
+        const float scale = bound > 0.f ? 1073741824.0f / bound : 0.f;
+        q_scale[qi] = scale;
+        q_eps[qi] = scale > 0.f ? (float)(t1 - t0 + 1) / scale : 0.f;
+    }
+}
+
+// ---- scan: grid (n_ranges, B), 1024 threads -------------------------------------
+// The block owns docs [range*16384, +16384) of one query: accumulators live in
+// LDS (64 KiB; two blocks per CU), every posting of the query's terms inside
+// the range is applied with an LDS integer atomic, and only the per-64-doc
+// maxima leave the CU.  Work is cut into items of kItemPostings consecutive
+// postings of one run; each wave takes items in a strided loop, kItemsInFlight
+// at a time, so it keeps 8 independent coalesced loads in flight instead of one.
 // Algorithmic HBM bytes per (query, range): sum over query terms of run_len * 6
-// (uint16 doc + fp32 weight) + 2*4 per term for the run bounds + 64*4 out.
-__global__ __launch_bounds__(256) void sparse_scan_kernel(
+// (uint16 doc + fp32 weight) + 2*4 per term for the run bounds + 256*4 out.
+constexpr int kItemPostings = 64;
+constexpr int kItemsInFlight = 8;
+constexpr int kItemTable = 4096;  // items whose run is looked up from a table instead of searched
+
+__device__ inline int fixed_contrib(float p) {  // round away from zero, branch-free
+    const int a = __float2int_ru(fabsf(p));
+    return p < 0.f ? -a : a;
+}
+// Accumulator index with one pad word per 64 docs: the per-group maxima then
+// read 64 different banks instead of one.
+__device__ inline int acc_index(int d) { return d + (d >> 6); }
+
+__global__ __launch_bounds__(1024) void sparse_scan_kernel(
     const unsigned int* __restrict__ rt_off, int64_t V1, const int64_t* __restrict__ range_base,
     const uint16_t* __restrict__ post_doc, const float* __restrict__ post_val,
     const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
-    const float* __restrict__ q_val, const uint8_t* __restrict__ rowmask, int64_t n_docs,
-    int64_t n_groups, float* __restrict__ gmax) {
-    __shared__ float acc[kRangeDocs];
-    __shared__ unsigned int run_lo[kScanTermChunk];
-    __shared__ unsigned int run_pre[kScanTermChunk + 1];  // exclusive prefix of run lengths
+    const float* __restrict__ q_val, const float* __restrict__ q_scale, const uint8_t* __restrict__ rowmask,
+    int64_t n_docs, int64_t n_groups, float* __restrict__ gmax) {
+    __shared__ int acc[kRangeDocs + kRangeDocs / 64];
+    __shared__ uint8_t item_run[kItemTable];
+    __shared__ unsigned int run_lo[kScanTermChunk], run_hi[kScanTermChunk];
+    __shared__ unsigned int item_pre[kScanTermChunk + 1];  // exclusive prefix of items per run
     __shared__ float run_w[kScanTermChunk];
+    __shared__ unsigned int wsum[16];
     const int64_t range = blockIdx.x;
     const int qi = blockIdx.y;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < kRangeDocs; i += 256) acc[i] = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        int4* a4 = reinterpret_cast<int4*>(acc);
+        for (int i = tid; i < (kRangeDocs + kRangeDocs / 64) / 4; i += 1024) a4[i] = make_int4(0, 0, 0, 0);
+    }
     const unsigned int* offs = rt_off + range * V1;
-    const int64_t base = range_base[range];
+    const uint16_t* pd = post_doc + range_base[range];
+    const float* pv = post_val + range_base[range];
     const int64_t t0 = q_indptr[qi], t1 = q_indptr[qi + 1];
+    const float scale = q_scale[qi];
 
     for (int64_t tc = t0; tc < t1; tc += kScanTermChunk) {
         const int nt = (int)((t1 - tc) < kScanTermChunk ? (t1 - tc) : kScanTermChunk);
         __syncthreads();
-        unsigned int len = 0;
+        unsigned int items = 0;
         if (tid < nt) {
-            int32_t t = q_idx[tc + tid];
-            unsigned int lo = offs[t], hi = offs[t + 1];
+            const int32_t t = q_idx[tc + tid];
+            const unsigned int lo = offs[t], hi = offs[t + 1];
             run_lo[tid] = lo;
-            run_w[tid] = q_val[tc + tid];
-            len = hi - lo;
+            run_hi[tid] = hi;
+            run_w[tid] = q_val[tc + tid] * scale;
+            items = (hi - lo + kItemPostings - 1) / kItemPostings;
         }
-        // block exclusive scan of len over 256 threads
-        {
-            __shared__ unsigned int wsum[4];
-            const int lane = tid & 63, w = tid >> 6;
-            unsigned int x = len;
+        // exclusive scan of `items` over the first 256 threads (4 waves)
+        unsigned int x = items;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                unsigned int y = __shfl_up(x, off);
-                if (lane >= off) x += y;
-            }
-            if (lane == 63) wsum[w] = x;
-            __syncthreads();
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned int y = __shfl_up(x, off);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        if (tid < kScanTermChunk) {
             unsigned int wbase = 0;
-            for (int j = 0; j < w; ++j) wbase += wsum[j];
-            run_pre[tid] = wbase + x - len;
-            if (tid == 255) run_pre[256] = wbase + x;
+            for (int j = 0; j < wave; ++j) wbase += wsum[j];
+            item_pre[tid] = wbase + x - items;
+            if (tid == kScanTermChunk - 1) item_pre[kScanTermChunk] = wbase + x;
         }
         __syncthreads();
-        const unsigned int total = run_pre[256];
-        for (unsigned int p = tid; p < total; p += 256) {
-            // largest i with run_pre[i] <= p
-            int lo = 0, hi = nt - 1;
-            while (lo < hi) {
-                int mid = (lo + hi + 1) >> 1;
-                if (run_pre[mid] <= p) lo = mid; else hi = mid - 1;
+        const unsigned int total_items = item_pre[kScanTermChunk];
+        if (tid < nt) {  // run of each of the first kItemTable items
+            const unsigned int first = item_pre[tid];
+            for (unsigned int c = 0; c < items && first + c < kItemTable; ++c) item_run[first + c] = (uint8_t)tid;
+        }
+        __syncthreads();
+
+        for (unsigned int base = wave; base < total_items; base += 16 * kItemsInFlight) {
+            unsigned int e[kItemsInFlight];
+            bool ok[kItemsInFlight];
+            float w[kItemsInFlight];
+#pragma unroll
+            for (int u = 0; u < kItemsInFlight; ++u) {
+                const unsigned int item = base + 16 * u;
+                ok[u] = false;
+                e[u] = 0;
+                w[u] = 0.f;
+                if (item < total_items) {
+                    int lo;
+                    if (item < kItemTable) {
+                        lo = item_run[item];
+                    } else {  // largest r with item_pre[r] <= item (wave-uniform)
+                        lo = 0;
+                        int hi = nt - 1;
+                        while (lo < hi) {
+                            const int mid = (lo + hi + 1) >> 1;
+                            if (item_pre[mid] <= item) lo = mid; else hi = mid - 1;
+                        }
+                    }
+                    e[u] = run_lo[lo] + (item - item_pre[lo]) * kItemPostings + lane;
+                    ok[u] = e[u] < run_hi[lo];
+                    w[u] = run_w[lo];
+                }
             }
-            const int64_t e = base + run_lo[lo] + (p - run_pre[lo]);
-            atomicAdd(&acc[post_doc[e]], run_w[lo] * post_val[e]);
+            uint16_t d[kItemsInFlight];
+            float v[kItemsInFlight];
+#pragma unroll
+            for (int u = 0; u < kItemsInFlight; ++u) {  // every load is issued before the first use
+                d[u] = ok[u] ? pd[e[u]] : (uint16_t)0;
+                v[u] = ok[u] ? pv[e[u]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < kItemsInFlight; ++u)
+                if (ok[u]) atomicAdd(&acc[acc_index(d[u])], fixed_contrib(w[u] * v[u]));
         }
     }
     __syncthreads();
-    // per-group maxima: thread = (group, sub) with 4 threads per group
+    // per-group maxima: 256 groups, 4 threads per group
     {
         const int grp = tid >> 2, sub = tid & 3;
-        float m = 0.f;
+        int m = 0;
         const int64_t doc0 = range * kRangeDocs + grp * kGroupRows;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            int local = j * 4 + sub;
-            float v = acc[grp * kGroupRows + local];
+            const int local = j * 4 + sub;
+            int v = acc[acc_index(grp * kGroupRows + local)];
             if (rowmask) {
-                int64_t d = doc0 + local;
-                if (d < n_docs && !((rowmask[d >> 3] >> (d & 7)) & 1)) v = 0.f;
+                const int64_t dd = doc0 + local;
+                if (dd < n_docs && !((rowmask[dd >> 3] >> (dd & 7)) & 1)) v = 0;
             }
-            m = fmaxf(m, v);
+            m = max(m, v);
         }
-        m = fmaxf(m, __shfl_xor(m, 1));
-        m = fmaxf(m, __shfl_xor(m, 2));
+        m = max(m, __shfl_xor(m, 1));
+        m = max(m, __shfl_xor(m, 2));
         const int64_t group = range * kRangeGroups + grp;
-        if (sub == 0 && group < n_groups) gmax[(int64_t)qi * n_groups + group] = m;
+        if (sub == 0 && group < n_groups) gmax[(int64_t)qi * n_groups + group] = scale > 0.f ? (float)m / scale : 0.f;
     }
 }
 
 // ---- refine: one wave per (query, candidate group); lane = doc -------------------
 // Canonical score: walk the doc's CSR entries in stored order, look each index
 // up in the query's sorted terms, accumulate exact products in fp64.
-// Restated in oracle/oracle.c:sparse_score().
-__global__ __launch_bounds__(64) void refine_sparse_kernel(
+// Restated in oracle/oracle.c:oracle_sparse_scores().
+// The block (4 waves = 4 candidate groups of one query) stages the query in LDS
+// together with a 32768-bit hashed membership filter, so the ~99 % of entries
+// that cannot match cost one LDS read instead of a binary search.
+constexpr int kFilterBits = 32768;
+
+__global__ __launch_bounds__(256) void refine_sparse_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
     const float* __restrict__ q_val, const uint8_t* __restrict__ rowmask,
     const int32_t* __restrict__ cand, int C, int64_t n_docs, float* __restrict__ out_score,
     int32_t* __restrict__ out_row) {
-    const int qi = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
+    __shared__ int32_t s_idx[HR_MAX_QUERY_NNZ];
+    __shared__ float s_val[HR_MAX_QUERY_NNZ];
+    __shared__ unsigned int s_filter[kFilterBits / 32];
+    const int qi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int ci = blockIdx.x * 4 + (tid >> 6);
+    const int64_t t0 = q_indptr[qi];
+    const int nt = min((int)(q_indptr[qi + 1] - t0), HR_MAX_QUERY_NNZ);
+    for (int i = tid; i < kFilterBits / 32; i += 256) s_filter[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nt; i += 256) {
+        const int32_t t = q_idx[t0 + i];
+        s_idx[i] = t;
+        s_val[i] = q_val[t0 + i];
+        atomicOr(&s_filter[(t & (kFilterBits - 1)) >> 5], 1u << (t & 31));
+    }
+    __syncthreads();
+    if (ci >= C) return;
     const int32_t group = cand[(int64_t)qi * C + ci];
     const int64_t o = ((int64_t)qi * C + ci) * kGroupRows + lane;
     const int64_t doc = (int64_t)group * kGroupRows + lane;
@@ -186,19 +293,17 @@ __global__ __launch_bounds__(64) void refine_sparse_kernel(
     if (valid && rowmask) valid = (rowmask[doc >> 3] >> (doc & 7)) & 1;
     float score = 0.f;
     if (valid) {
-        const int64_t t0 = q_indptr[qi];
-        const int nt = (int)(q_indptr[qi + 1] - t0);
-        const int32_t* qi_idx = q_idx + t0;
-        const float* qi_val = q_val + t0;
         double s = 0.0;
-        for (int64_t e = indptr[doc]; e < indptr[doc + 1]; ++e) {
+        const int64_t e1 = indptr[doc + 1];
+        for (int64_t e = indptr[doc]; e < e1; ++e) {
             const int32_t t = idx[e];
-            int lo = 0, hi = nt;  // first position with qi_idx[pos] >= t
+            if (!((s_filter[(t & (kFilterBits - 1)) >> 5] >> (t & 31)) & 1u)) continue;
+            int lo = 0, hi = nt;  // first position with s_idx[pos] >= t
             while (lo < hi) {
-                int mid = (lo + hi) >> 1;
-                if (qi_idx[mid] < t) lo = mid + 1; else hi = mid;
+                const int mid = (lo + hi) >> 1;
+                if (s_idx[mid] < t) lo = mid + 1; else hi = mid;
             }
-            if (lo < nt && qi_idx[lo] == t) s = __dadd_rn(s, __dmul_rn((double)val[e], (double)qi_val[lo]));
+            if (lo < nt && s_idx[lo] == t) s = __dadd_rn(s, __dmul_rn((double)val[e], (double)s_val[lo]));
         }
         score = (float)s;
     }

@@ -15,9 +15,8 @@ def _bits(a):
 def make_sparse(rng, n, V, nnz):
     """Reference placeholder shape (indexing.py:647-654): nnz distinct indices, |N(0,1)| values, sorted."""
     indptr = np.arange(n + 1, dtype=np.int64) * nnz
-    idx = np.empty(n * nnz, dtype=np.int32)
-    for r in range(n):
-        idx[r * nnz:(r + 1) * nnz] = np.sort(rng.choice(V, size=nnz, replace=False))
+    # nnz distinct indices per row: the nnz smallest of V random keys
+    idx = np.sort(np.argpartition(rng.random((n, V)), nnz - 1, axis=1)[:, :nnz], axis=1).astype(np.int32).reshape(-1)
     val = np.abs(rng.standard_normal(n * nnz)).astype(np.float32)
     return indptr, idx, val
 
@@ -31,7 +30,8 @@ def make_queries(rng, B, V, nnz):
 
 
 @pytest.mark.parametrize("n,V,nnz,B,k,drop", [(500, 1000, 20, 3, 10, 0.0), (5000, 10000, 100, 8, 40, 0.2),
-                                               (9000, 2000, 30, 17, 40, 0.2), (70, 50, 5, 4, 100, 0.5)])
+                                               (9000, 2000, 30, 17, 40, 0.2), (70, 50, 5, 4, 100, 0.5),
+                                               (40000, 500, 12, 5, 40, 0.2), (33000, 60, 6, 3, 200, 0.0)])
 def test_sparse_matches_oracle(gpu, n, V, nnz, B, k, drop):
     rng = np.random.default_rng(n + V)
     indptr, idx, val = make_sparse(rng, n, V, nnz)
