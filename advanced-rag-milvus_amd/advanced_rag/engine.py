@@ -63,6 +63,48 @@ def pack_sparse_queries(queries: Sequence[Tuple[Sequence[int], Sequence[float]]]
     return np.asarray(ptr, np.int64), idx.astype(np.int32), val.astype(np.float32), max_nnz
 
 
+@dataclass(frozen=True)
+class ListPack:
+    """Byte layout of one rank's slot in the all-gather buffer: the ids of every
+    modality ([n_mod][B][kp] int64) followed by their scores ([n_mod][B][kp] fp32).
+    Backend-agnostic (torch uint8 tensors on any device) so the gloo CPU tests
+    exercise exactly the offsets and strides the HIP merge kernel is given."""
+    n_mod: int
+    B: int
+    kp: int
+
+    @property
+    def id_bytes(self) -> int:
+        return self.n_mod * self.B * self.kp * 8
+
+    @property
+    def nbytes(self) -> int:
+        return self.id_bytes + self.n_mod * self.B * self.kp * 4
+
+    def views(self, pack):
+        """(ids int64 [n_mod,B,kp], scores float32 [n_mod,B,kp]) views of a 1-D uint8 tensor."""
+        import torch
+        ids = pack[: self.id_bytes].view(torch.int64).view(self.n_mod, self.B, self.kp)
+        scores = pack[self.id_bytes: self.nbytes].view(torch.float32).view(self.n_mod, self.B, self.kp)
+        return ids, scores
+
+    def merge_args(self, modality: int):
+        """(score byte offset, id byte offset, score stride [floats], id stride [int64s]) of one
+        modality inside a gathered [world, nbytes] buffer."""
+        return (self.id_bytes + modality * self.B * self.kp * 4, modality * self.B * self.kp * 8,
+                self.nbytes // 4, self.nbytes // 8)
+
+
+def exchange_lists(pack, world: int, dist=None, group=None, out=None):
+    """All-gather every rank's packed lists: returns a [world, nbytes] uint8 tensor
+    (one collective per query batch; RCCL on GPUs, gloo in the CPU tests)."""
+    import torch
+    if out is None:
+        out = torch.empty((world, pack.numel()), dtype=torch.uint8, device=pack.device)
+    dist.all_gather_into_tensor(out.view(-1), pack, group=group)
+    return out
+
+
 @dataclass
 class EngineConfig:
     top_k: int = 20
@@ -102,12 +144,13 @@ class HybridSearchEngine:
         t, dev, cfg = self.torch, self.device, self.cfg
         kp = 2 * cfg.top_k
         n_mod = 2 if cfg.use_sparse else 1
-        id_bytes, sc_bytes = n_mod * B * kp * 8, n_mod * B * kp * 4
-        pack = t.zeros(id_bytes + sc_bytes, dtype=t.uint8, device=dev)
+        layout = ListPack(n_mod, B, kp)
+        pack = t.zeros(layout.nbytes, dtype=t.uint8, device=dev)
+        ids_v, scores_v = layout.views(pack)
         b = {
-            "kp": kp, "n_mod": n_mod, "pack": pack, "id_bytes": id_bytes,
-            "ids": pack[:id_bytes].view(t.int64).view(n_mod, B, kp),
-            "scores": pack[id_bytes:].view(t.float32).view(n_mod, B, kp),
+            "kp": kp, "n_mod": n_mod, "pack": pack, "layout": layout,
+            "ids": ids_v,
+            "scores": scores_v,
             "flags": t.zeros((n_mod, B), dtype=t.int32, device=dev),
             "fused_ids": t.empty((B, cfg.top_k), dtype=t.int64, device=dev),
             "fused_scores": t.empty((B, cfg.top_k), dtype=t.float64, device=dev),
@@ -118,7 +161,7 @@ class HybridSearchEngine:
             "rr_orig": t.empty((B, cfg.rerank_top_k), dtype=t.float64, device=dev),
         }
         if self.world > 1:
-            b["gathered"] = t.empty((self.world, id_bytes + sc_bytes), dtype=t.uint8, device=dev)
+            b["gathered"] = t.empty((self.world, layout.nbytes), dtype=t.uint8, device=dev)
             b["m_ids"] = t.empty((n_mod, B, kp), dtype=t.int64, device=dev)
             b["m_scores"] = t.empty((n_mod, B, kp), dtype=t.float32, device=dev)
         self._bufs[B] = b
@@ -143,15 +186,12 @@ class HybridSearchEngine:
                                      b["flags"][1].data_ptr(), 0, stream)
         ids, scores = b["ids"], b["scores"]
         if self.world > 1:
-            g = b["gathered"]
-            self.dist.all_gather_into_tensor(g.view(-1), b["pack"], group=self.group)
-            total = g.shape[1]
+            g = exchange_lists(b["pack"], self.world, self.dist, self.group, out=b["gathered"])
             for m in range(b["n_mod"]):
-                id_off = m * B * kp * 8
-                sc_off = b["id_bytes"] + m * B * kp * 4
+                sc_off, id_off, sc_stride, id_stride = b["layout"].merge_args(m)
                 nat.merge_topk_dev(g.data_ptr() + sc_off, g.data_ptr() + id_off, self.world, B, kp, kp,
                                    b["m_ids"][m].data_ptr(), b["m_scores"][m].data_ptr(), stream,
-                                   score_stride=total // 4, id_stride=total // 8)
+                                   score_stride=sc_stride, id_stride=id_stride)
             ids, scores = b["m_ids"], b["m_scores"]
         nat.fuse_rrf_dev(ids[0].data_ptr(), kp, ids[1].data_ptr() if cfg.use_sparse else 0,
                          kp if cfg.use_sparse else 0, 0, 0, B, cfg.dense_weight, cfg.sparse_weight, 0.2, cfg.rrf_k,

@@ -1,0 +1,123 @@
+"""The N>1 path on CPU: two gloo ranks each hold a row shard, build their local top-k' lists
+(CPU oracle standing in for the per-shard HIP search), exchange them with the engine's own
+pack layout + all-gather, and merge with the offsets/strides the HIP merge kernel is given.
+Every rank must end up with the global oracle's lists."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _corpus(n=5003, d=48, V=400, nnz=9, B=6):
+    rng = np.random.default_rng(99)
+    X = rng.standard_normal((n, d)).astype(np.float16)
+    X[100] = X[4000]  # an exact cross-shard tie
+    idx = np.sort(np.argpartition(rng.random((n, V)), nnz - 1, axis=1)[:, :nnz], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * nnz)).astype(np.float32)
+    ptr = np.arange(n + 1, dtype=np.int64) * nnz
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[0] = X[100].astype(np.float32)
+    SQ = [(np.sort(rng.choice(V, 30, replace=False)).astype(np.int32), np.abs(rng.standard_normal(30)).astype(np.float32))
+          for _ in range(B)]
+    return X, ptr, idx, val, Q, SQ
+
+
+def _merge_numpy(gathered, layout, world, m):
+    """numpy restatement of csrc/fuse.h merge_topk_kernel on the gathered byte buffer."""
+    sc_off, id_off, sc_stride, id_stride = layout.merge_args(m)
+    raw = gathered.numpy().reshape(-1)
+    out_ids = np.empty((layout.B, layout.kp), np.int64)
+    out_sc = np.empty((layout.B, layout.kp), np.float32)
+    for q in range(layout.B):
+        ids, scs = [], []
+        for w in range(world):
+            a = id_off + w * id_stride * 8 + q * layout.kp * 8
+            ids.append(raw[a:a + layout.kp * 8].view(np.int64))
+            a = sc_off + w * sc_stride * 4 + q * layout.kp * 4
+            scs.append(raw[a:a + layout.kp * 4].view(np.float32))
+        ids, scs = np.concatenate(ids), np.concatenate(scs)
+        keep = ids >= 0
+        order = np.lexsort((ids[keep], -scs[keep]))[:layout.kp]
+        out_ids[q], out_sc[q] = -1, 0.0
+        out_ids[q, :len(order)] = ids[keep][order]
+        out_sc[q, :len(order)] = scs[keep][order]
+    return out_ids, out_sc
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "advanced-rag-milvus_amd"))
+    import oracle
+    from advanced_rag.engine import ListPack, exchange_lists, shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, ptr, idx, val, Q, SQ = _corpus()
+        n, kp, B = X.shape[0], 40, Q.shape[0]
+        lo, hi = shard_range(n, rank, world, align=64)
+        layout = ListPack(2, B, kp)
+        pack = torch.zeros(layout.nbytes, dtype=torch.uint8)
+        ids, scores = layout.views(pack)
+        di, ds = oracle.dense_search(X[lo:hi], Q, kp, oracle.COSINE, row_offset=lo)
+        lp = ptr[lo:hi + 1] - ptr[lo]
+        si, ss = oracle.sparse_search(lp, idx[ptr[lo]:ptr[hi]], val[ptr[lo]:ptr[hi]], SQ, kp, 0.2, row_offset=lo)
+        ids[0], scores[0] = torch.from_numpy(di), torch.from_numpy(ds)
+        ids[1], scores[1] = torch.from_numpy(si), torch.from_numpy(ss)
+        g = exchange_lists(pack, world, dist)
+        assert g.shape == (world, layout.nbytes)
+        gd = oracle.dense_search(X, Q, kp, oracle.COSINE)
+        gs = oracle.sparse_search(ptr, idx, val, SQ, kp, 0.2)
+        for m, (want_i, want_s) in enumerate((gd, gs)):
+            got_i, got_s = _merge_numpy(g, layout, world, m)
+            assert np.array_equal(got_i, want_i), f"rank {rank} modality {m}"
+            assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
+        assert set(gd[0][0, :2].tolist()) == {100, 4000}  # the tie pair spans both shards, lower id first
+        assert gd[0][0, 0] == 100
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_exchange_and_merge_matches_global_oracle():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def test_shard_range_partitions_rows():
+    from advanced_rag.engine import shard_range
+    for n, w, a in ((10_000_000, 8, 250_000), (10, 4, 1), (1000, 3, 64), (5, 8, 1), (0, 2, 1)):
+        spans = [shard_range(n, r, w, a) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        assert all(lo % a == 0 or lo == n for lo, _ in spans)
+
+
+def test_pack_sparse_queries_matches_oracle_drop():
+    import oracle
+    from advanced_rag.engine import pack_sparse_queries
+    rng = np.random.default_rng(4)
+    qs = [(rng.permutation(500)[:n].astype(np.int32), np.round(np.abs(rng.standard_normal(n)), 1).astype(np.float32))
+          for n in (0, 1, 7, 100)]
+    ptr, idx, val, mx = pack_sparse_queries(qs, 0.2)
+    for b, (qi, qv) in enumerate(qs):
+        oi, ov = oracle.drop_query(qi, qv, 0.2)
+        assert np.array_equal(idx[ptr[b]:ptr[b + 1]], oi) and np.array_equal(val[ptr[b]:ptr[b + 1]], ov)
+    assert mx == 80

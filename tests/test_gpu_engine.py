@@ -1,0 +1,183 @@
+"""The batched device path (engine.HybridSearchEngine: dense + sparse + RRF + rerank, all HIP
+kernels on one stream) against the oracle, and the cross-shard merge with the all-gather buffer
+layout: two shards on one GPU stand in for two ranks."""
+import numpy as np
+import pytest
+
+import oracle
+from advanced_rag import _native as nat
+from advanced_rag.engine import EngineConfig, HybridSearchEngine, ListPack, pack_sparse_queries, shard_range
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def corpus(n, d, V, nnz, B, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d)).astype(np.float16)
+    idx = np.sort(np.argpartition(rng.random((n, V)), nnz - 1, axis=1)[:, :nnz], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * nnz)).astype(np.float32)
+    ptr = np.arange(n + 1, dtype=np.int64) * nnz
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    SQ = [(np.sort(rng.choice(V, 3 * nnz, replace=False)).astype(np.int32),
+           np.abs(rng.standard_normal(3 * nnz)).astype(np.float32)) for _ in range(B)]
+    return X, ptr, idx, val, Q, SQ
+
+
+def oracle_pipeline(X, ptr, idx, val, Q, SQ, cfg):
+    kp = 2 * cfg.top_k
+    di, ds = oracle.dense_search(X, Q, kp, oracle.COSINE)
+    si, ss = oracle.sparse_search(ptr, idx, val, SQ, kp, 0.2)
+    fused, reranked = [], []
+    for b in range(Q.shape[0]):
+        fi, fs, fm = oracle.rrf(di[b], si[b][si[b] >= 0], (), cfg.dense_weight, cfg.sparse_weight, 0.2, cfg.rrf_k)
+        fi, fs, fm = fi[:cfg.top_k], fs[:cfg.top_k], fm[:cfg.top_k]
+        fused.append((fi, fs, fm))
+        new = [cfg.base_weight * float(s) + cfg.method_bonus * float(bin(int(m)).count("1")) + cfg.recency_weight * 0.0
+               for s, m in zip(fs, fm)]
+        order = sorted(range(len(new)), key=lambda i: new[i], reverse=True)[:cfg.rerank_top_k]  # stable, like list.sort
+        reranked.append((fi[order], np.array([new[i] for i in order]), fs[order]))
+    return (di, ds), (si, ss), fused, reranked
+
+
+@pytest.mark.parametrize("n,d,V,nnz,B,top_k", [(6000, 128, 800, 12, 9, 20), (20000, 768, 10000, 100, 64, 20),
+                                                (300, 64, 100, 5, 3, 50)])
+def test_engine_single_shard_matches_oracle(gpu, n, d, V, nnz, B, top_k):
+    X, ptr, idx, val, Q, SQ = corpus(n, d, V, nnz, B, seed=n)
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    h.add_dense(X)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    cfg = EngineConfig(top_k=top_k)
+    eng = HybridSearchEngine(h, cfg)
+    out = eng.search(torch.from_numpy(Q).cuda(), eng.upload_sparse(pack_sparse_queries(SQ, 0.2)))
+    torch.cuda.synchronize()
+    (di, ds), (si, ss), fused, reranked = oracle_pipeline(X, ptr, idx, val, Q, SQ, cfg)
+    assert out["flags"].min().item() == 1
+    assert np.array_equal(out["ids"][0].cpu().numpy(), di) and np.array_equal(out["ids"][1].cpu().numpy(), si)
+    assert np.array_equal(out["scores"][0].cpu().numpy().view(np.uint32), ds.view(np.uint32))
+    assert np.array_equal(out["scores"][1].cpu().numpy().view(np.uint32), ss.view(np.uint32))
+    for b in range(B):
+        fi, fs, fm = fused[b]
+        nf = int(out["fused_n"][b])
+        assert nf == len(fi)
+        assert np.array_equal(out["fused_ids"][b, :nf].cpu().numpy(), fi)
+        assert np.array_equal(out["fused_scores"][b, :nf].cpu().numpy().view(np.uint64), fs.view(np.uint64))
+        assert np.array_equal(out["fused_methods"][b, :nf].cpu().numpy(), fm)
+        ri, rs, ro = reranked[b]
+        nr = len(ri)
+        assert np.array_equal(out["rr_ids"][b, :nr].cpu().numpy(), ri)
+        assert np.array_equal(out["rr_scores"][b, :nr].cpu().numpy().view(np.uint64), rs.view(np.uint64))
+        assert np.array_equal(out["rr_orig"][b, :nr].cpu().numpy().view(np.uint64), ro.view(np.uint64))
+    h.close()
+
+
+def test_two_shards_merge_equals_global(gpu):
+    n, d, V, nnz, B, kp = 9000, 96, 600, 10, 7, 40
+    X, ptr, idx, val, Q, SQ = corpus(n, d, V, nnz, B, seed=5)
+    X[17] = X[8000]  # cross-shard tie
+    world = 2
+    layout = ListPack(2, B, kp)
+    gathered = torch.zeros((world, layout.nbytes), dtype=torch.uint8, device="cuda")
+    handles = []
+    dq = torch.from_numpy(Q).cuda()
+    p, i_, v_, mx = pack_sparse_queries(SQ, 0.2)
+    dp, di_, dv_ = torch.from_numpy(p).cuda(), torch.from_numpy(i_).cuda(), torch.from_numpy(v_).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    for r in range(world):
+        lo, hi = shard_range(n, r, world, align=64)
+        h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+        h.set_row_offset(lo)
+        h.add_dense(X[lo:hi])
+        h.add_sparse(ptr[lo:hi + 1] - ptr[lo], idx[ptr[lo]:ptr[hi]], val[ptr[lo]:ptr[hi]])
+        h.finalize()
+        ids, scores = layout.views(gathered[r])
+        h.search_dense_dev(dq.data_ptr(), B, kp, ids[0].data_ptr(), scores[0].data_ptr(), 0, 0, st)
+        h.search_sparse_dev(dp.data_ptr(), di_.data_ptr(), dv_.data_ptr(), B, len(i_), mx, kp, ids[1].data_ptr(),
+                            scores[1].data_ptr(), 0, 0, st)
+        handles.append(h)
+    gd = oracle.dense_search(X, Q, kp, oracle.COSINE)
+    gs = oracle.sparse_search(ptr, idx, val, SQ, kp, 0.2)
+    for m, (want_i, want_s) in enumerate((gd, gs)):
+        oi = torch.empty((B, kp), dtype=torch.int64, device="cuda")
+        os_ = torch.empty((B, kp), dtype=torch.float32, device="cuda")
+        sc_off, id_off, sc_stride, id_stride = layout.merge_args(m)
+        nat.merge_topk_dev(gathered.data_ptr() + sc_off, gathered.data_ptr() + id_off, world, B, kp, kp, oi.data_ptr(),
+                           os_.data_ptr(), st, score_stride=sc_stride, id_stride=id_stride)
+        torch.cuda.synchronize()
+        assert np.array_equal(oi.cpu().numpy(), want_i)
+        assert np.array_equal(os_.cpu().numpy().view(np.uint32), want_s.view(np.uint32))
+    for h in handles:
+        h.close()
+
+
+def test_index_manager_and_retriever_on_gpu(gpu):
+    """The reference-shaped API end to end on the device: index_chunks -> retrieve (device RRF) -> filters -> delete."""
+    import asyncio
+    from advanced_rag import (AdvancedRAGPipeline, BM25SparseEncoder, HybridRetriever, MilvusIndexManager, PipelineConfig,
+                              RetrievalConfig)
+    from advanced_rag.constants import RetrievalConstants
+    from advanced_rag.embedding_cache import initialize_caches
+    from advanced_rag.retrieval import rrf_rank_lists
+
+    initialize_caches()
+    docs = [{"id": f"d{i}", "text": f"Document {i} talks about topic{i % 7} and widget{i % 5}. " * 3 + "Shared filler sentence here.",
+             "metadata": {"source": "unit"}} for i in range(60)]
+    rng = np.random.default_rng(0)
+    table = {}
+
+    class Gen:
+        def __init__(self):
+            self.bm25 = BM25SparseEncoder(sparse_dim=2048)
+
+        def encode_semantic(self, text):
+            if text not in table:
+                table[text] = rng.standard_normal(64).astype(np.float32)
+            return table[text]
+
+        def encode_sparse(self, text):
+            return self.bm25.encode_document(text)
+
+        def encode_sparse_query(self, text):
+            return self.bm25.encode_query(text)
+
+        def encode_domain(self, text, domain=None):
+            return self.encode_semantic(text)[:32].copy()
+
+    gen = Gen()
+    p = AdvancedRAGPipeline(config=PipelineConfig(enable_audit_logging=False), semantic_dim=64, sparse_dim=2048,
+                            domain_dim=32)
+    p.index_manager.embedding_generator = gen
+    gen.bm25.fit(d["text"] for d in docs)
+    report = asyncio.run(p.ingest_documents(docs))
+    summ = report["indexing_summary"]
+    assert summ["indexed_semantic"] == summ["total_chunks"] == summ["indexed_sparse"] == summ["indexed_domain"] and not summ["errors"]
+    mgr = p.index_manager
+    assert mgr.get_collection_stats("semantic_index")["num_entities"] == summ["total_chunks"]
+    old = RetrievalConstants.TIMEOUT_SECONDS
+    RetrievalConstants.TIMEOUT_SECONDS = 30.0
+    try:
+        retr = HybridRetriever(mgr, RetrievalConfig(top_k=10))
+        query = mgr._cols["content"][7]
+        out = asyncio.run(retr.retrieve(query, profile_hint="default"))
+        assert out[0]["id"] == mgr._cols["id"][7] and set(out[0]["retrieval_methods"]) == {"semantic", "sparse"}
+        # device RRF == host RRF on the same lists
+        sem = asyncio.run(mgr.search(gen.encode_semantic(query), "semantic_index", 20))
+        sp = asyncio.run(mgr.search(gen.encode_sparse_query(query), "sparse_index", 20, None,
+                                    {"metric_type": "IP", "params": {"drop_ratio_search": 0.2}}))
+        host = rrf_rank_lists([[h["id"] for h in sem], [h["id"] for h in sp], []], [0.7, 0.3, 0.2], 60)
+        assert [o["id"] for o in out] == [h[0] for h in host][:10]
+        assert [o["score"] for o in out] == [h[1] for h in host][:10]
+        # filter expression -> row mask
+        doc7 = mgr._cols["doc_id"][7]
+        flt = asyncio.run(retr.retrieve(query, filters={"doc_id": doc7}, profile_hint="default"))
+        assert flt and all(o["metadata"]["doc_id"] == doc7 for o in flt)
+        # tombstones
+        asyncio.run(mgr.delete_by_filter("semantic_index", f'doc_id == "{doc7}"'))
+        gone = asyncio.run(retr.retrieve(query, profile_hint="default"))
+        assert all(o["metadata"]["doc_id"] != doc7 for o in gone)
+        results, metrics = asyncio.run(p.retrieve("topic3 widget2", context={"retrieval_profile": "default"}))
+        assert len(results) == 5 and results[0].chunk_id
+    finally:
+        RetrievalConstants.TIMEOUT_SECONDS = old
+        asyncio.run(p.close())
