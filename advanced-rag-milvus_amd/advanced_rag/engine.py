@@ -101,6 +101,12 @@ def exchange_lists(pack, world: int, dist=None, group=None, out=None):
     import torch
     if out is None:
         out = torch.empty((world, pack.numel()), dtype=torch.uint8, device=pack.device)
+    if pack.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (several ranks sharing one GPU): gloo has no device all-gather, stage through the host
+        host = torch.empty((world, pack.numel()), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host.view(-1), pack.cpu(), group=group)
+        out.copy_(host)
+        return out
     dist.all_gather_into_tensor(out.view(-1), pack, group=group)
     return out
 
@@ -121,7 +127,7 @@ class EngineConfig:
 
 class HybridSearchEngine:
     def __init__(self, handle: "nat.ShardHandle", config: Optional[EngineConfig] = None, process_group=None,
-                 device: Optional[str] = None):
+                 device: Optional[str] = None, stream=None):
         import torch
         self.torch = torch
         self.h = handle
@@ -134,6 +140,10 @@ class HybridSearchEngine:
             self.world = self.dist.get_world_size(process_group)
             self.rank = self.dist.get_rank(process_group)
         self.device = torch.device(device or f"cuda:{handle.device}")
+        # Optional private stream: several engines on different streams keep several query batches
+        # in flight, so the latency-bound tail of one batch (select / refine / exchange / fuse)
+        # overlaps the bandwidth-bound scans of the next.
+        self.stream = stream
         self._bufs: Dict[int, dict] = {}
 
     # ------------------------------------------------------------------ buffers
@@ -172,18 +182,23 @@ class HybridSearchEngine:
         """q: float32 [B, dim] device tensor.  sparse: (indptr int64[B+1], idx int32, val float32, max_nnz)
         device tensors from `upload_sparse`.  Asynchronous on the current stream; returns the
         buffer dict (fused_* and rr_* tensors are the results; they are reused by the next call)."""
+        if self.stream is not None and self.torch.cuda.current_stream(self.device) != self.stream:
+            with self.torch.cuda.stream(self.stream):
+                return self.search(q, sparse)
         t, cfg = self.torch, self.cfg
         B = q.shape[0]
         b = self._buffers(B)
         kp = b["kp"]
         stream = t.cuda.current_stream(self.device).cuda_stream
-        self.h.search_dense_dev(q.data_ptr(), B, kp, b["ids"][0].data_ptr(), b["scores"][0].data_ptr(),
-                                b["flags"][0].data_ptr(), 0, stream)
         if cfg.use_sparse:
             indptr, idx, val, max_nnz = sparse
-            self.h.search_sparse_dev(indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, int(idx.shape[0]),
-                                     int(max_nnz), kp, b["ids"][1].data_ptr(), b["scores"][1].data_ptr(),
-                                     b["flags"][1].data_ptr(), 0, stream)
+            # one call: dense scan alone on this stream, sparse chain overlapping the dense tail
+            self.h.search_hybrid_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B,
+                                     int(idx.shape[0]), int(max_nnz), kp, b["ids"].data_ptr(), b["scores"].data_ptr(),
+                                     b["flags"].data_ptr(), 0, stream)
+        else:
+            self.h.search_dense_dev(q.data_ptr(), B, kp, b["ids"][0].data_ptr(), b["scores"][0].data_ptr(),
+                                    b["flags"][0].data_ptr(), 0, stream)
         ids, scores = b["ids"], b["scores"]
         if self.world > 1:
             g = exchange_lists(b["pack"], self.world, self.dist, self.group, out=b["gathered"])

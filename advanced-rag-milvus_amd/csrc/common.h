@@ -12,8 +12,11 @@ typedef unsigned int chunk_t __attribute__((ext_vector_type(4)));  // one 16-byt
 
 constexpr int kWave = 64;
 constexpr int kRowsPerBlock = 16;   // rows of one MFMA A-tile ("row block")
-constexpr int kRowBlocksPerGroup = 4;  // row blocks whose max is kept as one candidate group
-constexpr int kGroupRows = kRowsPerBlock * kRowBlocksPerGroup;  // 64 rows: one refine wave
+constexpr int kRowBlocksPerSuper = 4;  // row blocks a scan wave takes per step of its grid-stride loop
+constexpr int kSuperRows = kRowsPerBlock * kRowBlocksPerSuper;  // 64 rows
+// Candidate-group size (rows whose scan maximum is kept as one value) is a per-shard
+// setting: 16 (one row block) or 64 (one super-group).  Smaller groups mean 4x less
+// refine traffic per query at the price of 4x more group maxima written by the scan.
 constexpr int kChunkBytes = 16;     // bytes one lane contributes to a tile
 constexpr int kTileChunks = 64;     // chunks (lanes) per 1 KiB tile
 

@@ -132,13 +132,18 @@ struct Mfma<float> {
 
 // PF = depth of the per-wave register prefetch ring (k-steps in flight); KT is
 // padded to a multiple of PF at hr_create so ring slots stay compile-time.
-template <typename STORE, int G, int RS, int PF>
+template <typename STORE, int G, int RS, int PF, int NRB>
 __global__ __launch_bounds__(512) void dense_scan_kernel(
     const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
     const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int KT, int64_t n_rows,
-    int64_t n_groups) {
+    int64_t n_super) {
+    // NRB = row blocks per candidate group: 4 (64-row groups) or 1 (16-row groups).
+    // `group` below walks SUPER-groups of 4 row blocks either way; gmax is [nq][n_super*4/NRB].
+    static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
+    const int64_t n_groups = n_super;  // loop bound (super-groups)
+    const int64_t gmax_stride = n_super * (kRowBlocksPerSuper / NRB);
     extern __shared__ chunk_t lds_q[];  // [G][KT][64] chunks
-    constexpr int kPairs = kRowBlocksPerGroup / RS;
+    constexpr int kPairs = kRowBlocksPerSuper / RS;
     const int nq_chunks = G * KT * kTileChunks;
     for (int i = threadIdx.x; i < nq_chunks; i += blockDim.x) lds_q[i] = qfrag[i];
     __syncthreads();
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
         // Unconditional load (no control flow around VMEM, so the compiler keeps
         // counted vmcnt waits): past the wave's last group re-read its first one.
         const int64_t grp = pf_group < n_groups ? pf_group : wave;
-        const int64_t rb = grp * kRowBlocksPerGroup + pf_pair * RS;
+        const int64_t rb = grp * kRowBlocksPerSuper + pf_pair * RS;
 #pragma unroll
         for (int s = 0; s < RS; ++s)
             ring[slot][s] = __builtin_nontemporal_load(tiles + ((rb + s) * KT + pf_kt) * kTileChunks + lane);
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
         float m[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) m[g] = NEG_INF;
-        const bool tail = (group + 1) * kGroupRows > n_rows || rowmask != nullptr;
+        const bool tail = (group + 1) * kSuperRows > n_rows || rowmask != nullptr;
 
 #pragma unroll 1
         for (int pair = 0; pair < kPairs; ++pair) {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
             // epilogue: lane holds rows row0..row0+3 of row block s for query 16g+(lane&15)
 #pragma unroll
             for (int s = 0; s < RS; ++s) {
-                const int64_t row0 = (group * kRowBlocksPerGroup + pair * RS + s) * kRowsPerBlock + quad * 4;
+                const int64_t row0 = (group * kRowBlocksPerSuper + pair * RS + s) * kRowsPerBlock + quad * 4;
                 const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(scale + row0);
                 float ok[4] = {1.f, 1.f, 1.f, 1.f};
                 if (tail) {
@@ -217,40 +222,54 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
                 }
 #pragma unroll
                 for (int g = 0; g < G; ++g) {
+                    float mr = NEG_INF;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[s][g][r] * sc[r];
                         v = (ok[r] != 0.f) ? v : NEG_INF;
-                        m[g] = fmaxf(m[g], v);
+                        mr = fmaxf(mr, v);
+                    }
+                    if (NRB == 1) {  // this row block is a candidate group of its own
+                        mr = fmaxf(mr, __shfl_xor(mr, 16));
+                        mr = fmaxf(mr, __shfl_xor(mr, 32));
+                        if (lane < 16 && 16 * g + lane < nq)
+                            gmax[(int64_t)(16 * g + lane) * gmax_stride + group * kRowBlocksPerSuper + pair * RS + s] = mr;
+                    } else {
+                        m[g] = fmaxf(m[g], mr);
                     }
                 }
             }
         }
+        if (NRB != 1) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            float v = m[g];
-            v = fmaxf(v, __shfl_xor(v, 16));
-            v = fmaxf(v, __shfl_xor(v, 32));
-            if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * n_groups + group] = v;
+            for (int g = 0; g < G; ++g) {
+                float v = m[g];
+                v = fmaxf(v, __shfl_xor(v, 16));
+                v = fmaxf(v, __shfl_xor(v, 32));
+                if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * gmax_stride + group] = v;
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// Canonical refine: one wave per (query, candidate group); lane = row.
+// Canonical refine: 64 candidate rows per wave (group_rows = 16 or 64 rows per candidate group); lane = row.
 // score = (float) S with S the k-ordered fp64 sum of exact products.  The same
 // arithmetic is restated in oracle/oracle.c:dense_score().
 template <typename STORE>
 __global__ __launch_bounds__(64) void refine_dense_kernel(
     const chunk_t* __restrict__ tiles, int KT, int dim, const float* __restrict__ q,
     const double* __restrict__ qn2, const double* __restrict__ norm2,
-    const uint8_t* __restrict__ rowmask, const int32_t* __restrict__ cand, int C, int64_t n_rows,
-    int cosine, float* __restrict__ out_score, int32_t* __restrict__ out_row) {
+    const uint8_t* __restrict__ rowmask, const int32_t* __restrict__ cand, int C, int group_rows,
+    int64_t n_rows, int cosine, float* __restrict__ out_score, int32_t* __restrict__ out_row) {
     constexpr int EPC = kChunkBytes / (int)sizeof(STORE);
-    const int qi = blockIdx.y, ci = blockIdx.x, lane = threadIdx.x;
-    const int32_t group = cand[(int64_t)qi * C + ci];
-    const int64_t o = ((int64_t)qi * C + ci) * kGroupRows + lane;
-    const int64_t row = (int64_t)group * kGroupRows + lane;
+    const int qi = blockIdx.y, lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;          // candidate row slot of this query
+    const int n_slots = C * group_rows;
+    if (slot >= n_slots) return;
+    const int32_t group = cand[(int64_t)qi * C + slot / group_rows];
+    const int64_t o = (int64_t)qi * n_slots + slot;
+    const int64_t row = (int64_t)group * group_rows + slot % group_rows;
     bool valid = group >= 0 && row < n_rows;
     if (valid && rowmask) valid = (rowmask[row >> 3] >> (row & 7)) & 1;
     if (!valid) {  // whole-wave exit is fine: no cross-lane ops below
@@ -260,13 +279,20 @@ __global__ __launch_bounds__(64) void refine_dense_kernel(
     }
     const float* qq = q + (int64_t)qi * dim;
     double s = 0.0;
-    for (int kc = 0; kc < KT * 4; ++kc) {
-        union { chunk_t v; STORE e[EPC]; } c;
-        c.v = tiles[chunk_index(row, kc, KT)];
+    // The fp64 add chain is serial by definition (canonical k order); the loads are not:
+    // fetch one whole 1 KiB-tile row slice (4 chunks) x 2 tiles per round trip.
+    constexpr int U = 8;
+    for (int kc0 = 0; kc0 < KT * 4; kc0 += U) {   // KT*4 is a multiple of 16
+        union { chunk_t v; STORE e[EPC]; } c[U];
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) {
-            int k = kc * EPC + j;
-            if (k < dim) s = __dadd_rn(s, __dmul_rn((double)c.e[j], (double)qq[k]));
+        for (int u = 0; u < U; ++u) c[u].v = tiles[chunk_index(row, kc0 + u, KT)];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                const int k = (kc0 + u) * EPC + j;
+                if (k < dim) s = __dadd_rn(s, __dmul_rn((double)c[u].e[j], (double)qq[k]));
+            }
         }
     }
     if (cosine) {

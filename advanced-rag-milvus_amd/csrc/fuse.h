@@ -24,22 +24,17 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(
     __shared__ int owner[kFuseMax];   // for b/c entries: slot of the first list entry with the same id, or -1
     __shared__ int slot_of[kFuseMax]; // insertion slot of entries that open a new id
     __shared__ int meth[kFuseMax];
-    __shared__ int s_na, s_nb, s_nc, s_new_b, s_new_c;
+    __shared__ int s_na, s_nb, s_nc, s_new_c;
     const int q = blockIdx.x, tid = threadIdx.x;
     const int64_t* la = ids_a + (int64_t)q * ka;
     const int64_t* lb = kb ? ids_b + (int64_t)q * kb : nullptr;
     const int64_t* lc = kc ? ids_c + (int64_t)q * kc : nullptr;
-    if (tid == 0) {
-        int n = 0;
-        while (n < ka && la[n] >= 0) ++n;
-        s_na = n;
-        n = 0;
-        while (n < kb && lb[n] >= 0) ++n;
-        s_nb = n;
-        n = 0;
-        while (n < kc && lc[n] >= 0) ++n;
-        s_nc = n;
-    }
+    // list lengths = position of the first negative id (lists are -1 padded at the tail)
+    if (tid == 0) { s_na = ka; s_nb = kb; s_nc = kc; }
+    __syncthreads();
+    for (int i = tid; i < ka; i += 256) if (la[i] < 0) atomicMin(&s_na, i);
+    for (int i = tid; i < kb; i += 256) if (lb[i] < 0) atomicMin(&s_nb, i);
+    for (int i = tid; i < kc; i += 256) if (lc[i] < 0) atomicMin(&s_nc, i);
     __syncthreads();
     const int na = s_na, nb = s_nb, nc = s_nc;
     // stage ids: [0,na) = a, [na, na+nb) = b, then c
@@ -63,17 +58,22 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(
         owner[na + nb + i] = o;
     }
     __syncthreads();
-    // insertion slots: a -> 0..na-1; new b ids follow in b order; new c ids after them
-    if (tid == 0) {
-        int s = na;
-        for (int i = 0; i < nb; ++i) slot_of[na + i] = (owner[na + i] < 0) ? s++ : -1;
-        s_new_b = s;
-        for (int i = 0; i < nc; ++i) slot_of[na + nb + i] = (owner[na + nb + i] < 0) ? s++ : -1;
-        s_new_c = s;
-    }
-    for (int i = tid; i < na; i += 256) slot_of[i] = i;
+    // insertion slots: a -> 0..na-1; new b ids follow in b order; new c ids after them.
+    // slot = na + #{earlier new entries}: counted per entry (lists are <= 256 long).
+    if (tid == 0) s_new_c = 0;
     __syncthreads();
-    const int n_ids = s_new_c;
+    for (int i = tid; i < na; i += 256) slot_of[i] = i;
+    for (int e = na + tid; e < na + nb + nc; e += 256) {
+        int sl = -1;
+        if (owner[e] < 0) {
+            sl = na;
+            for (int j = na; j < e; ++j) sl += owner[j] < 0;
+            atomicAdd(&s_new_c, 1);
+        }
+        slot_of[e] = sl;
+    }
+    __syncthreads();
+    const int n_ids = na + s_new_c;
     // scores, accumulated per owning entry in list order a, b, c
     for (int e = tid; e < na + nb + nc; e += 256) {
         if (owner[e] >= 0) continue;  // this entry's id was opened by an earlier list

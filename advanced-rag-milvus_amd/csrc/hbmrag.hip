@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -57,6 +58,9 @@ enum Phase { PH_PREP = 0, PH_SCAN, PH_GSEL, PH_REFINE, PH_TOPK, PH_SSCAN, PH_SGS
 
 struct Workspace {
     hipStream_t stream = nullptr;  // own stream (host-form calls)
+    hipStream_t side = nullptr;    // side stream + events of hr_search_hybrid_dev
+    hipEvent_t ev_scan = nullptr, ev_side = nullptr;
+    struct Workspace* sparse_ws = nullptr;  // private buffers of the sparse chain when it runs concurrently
     DevBuf qfrag, qn2, gmax, bmax, cand, acut, cscore, crow, flags, qscale, qeps;
     DevBuf d_q, d_ids, d_scores, d_mask;          // host-form staging
     DevBuf d_qptr, d_qidx, d_qval;                // sparse query staging
@@ -67,6 +71,16 @@ struct Workspace {
             b->release();
         if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
+        if (side) (void)hipStreamDestroy(side);
+        side = nullptr;
+        if (ev_scan) (void)hipEventDestroy(ev_scan);
+        if (ev_side) (void)hipEventDestroy(ev_side);
+        ev_scan = ev_side = nullptr;
+        if (sparse_ws) {
+            sparse_ws->release();
+            delete sparse_ws;
+            sparse_ws = nullptr;
+        }
     }
 };
 
@@ -82,6 +96,7 @@ struct hr_index {
     int64_t dim = 0, sparse_dim = 0;
     int dtype = HR_F16, metric = HR_METRIC_COSINE;
     int KT = 0;  // 1 KiB tiles per row block along k
+    int group_rows_override = 0;  // HBMRAG_GROUP_ROWS=16|64 pins the candidate-group size (default: by shard size)
     int64_t row_offset = 0;
 
     // dense shard
@@ -222,12 +237,21 @@ struct Span {
     }
 };
 
+// Rows (docs) per candidate group.  Small shards (a rank of a multi-GPU corpus) use 16-row
+// groups: 4x less refine traffic per query, and the 4x larger table of group maxima is
+// still small.  Big shards use 64-row groups, where selecting among 4x more maxima would
+// cost more than the refine saves (measured at 10M x 768: 3.88 ms/step vs 4.08).
+int group_rows_for(const hr_index* h, int64_t n) {
+    if (h->group_rows_override) return h->group_rows_override;
+    return n > 3000000 ? 64 : 16;
+}
+
 // ---- dense launch helpers ----------------------------------------------------
-template <typename STORE, int G>
+template <typename STORE, int G, int NRB>
 hipError_t launch_scan(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
                        int nq, int64_t n_groups) {
     constexpr int RS = 2, PF = 4;
-    auto kern = dense_scan_kernel<STORE, G, RS, PF>;
+    auto kern = dense_scan_kernel<STORE, G, RS, PF, NRB>;
     const size_t lds = (size_t)G * h->KT * 1024;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -253,11 +277,20 @@ hipError_t launch_scan(const hr_index* h, hipStream_t s, const chunk_t* qfrag, c
 template <typename STORE>
 hipError_t launch_scan_g(const hr_index* h, hipStream_t s, int G, const chunk_t* qfrag, const uint8_t* mask,
                          float* gmax, int nq, int64_t n_groups) {
+    // n_groups here counts SUPER-groups (64 rows) = the scan's loop bound
+    if (group_rows_for(h, h->n_rows) == 16) {
+        switch (G) {
+            case 1: return launch_scan<STORE, 1, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
+            case 2: return launch_scan<STORE, 2, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
+            case 3: return launch_scan<STORE, 3, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
+            default: return launch_scan<STORE, 4, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
+        }
+    }
     switch (G) {
-        case 1: return launch_scan<STORE, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
-        case 2: return launch_scan<STORE, 2>(h, s, qfrag, mask, gmax, nq, n_groups);
-        case 3: return launch_scan<STORE, 3>(h, s, qfrag, mask, gmax, nq, n_groups);
-        default: return launch_scan<STORE, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
+        case 1: return launch_scan<STORE, 1, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
+        case 2: return launch_scan<STORE, 2, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
+        case 3: return launch_scan<STORE, 3, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
+        default: return launch_scan<STORE, 4, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
     }
 }
 
@@ -312,8 +345,11 @@ void dense_eps(const hr_index* h, float* eps_abs, int* norm_mode) {
 
 // Enqueue a complete dense search on stream s.  All pointers are device pointers.
 int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float* d_q, int B, int k,
-                         const uint8_t* d_mask, int64_t* d_ids, float* d_scores, int32_t* d_flags, int C) {
-    const int64_t n_groups = (h->n_rows + kGroupRows - 1) / kGroupRows;
+                         const uint8_t* d_mask, int64_t* d_ids, float* d_scores, int32_t* d_flags, int C,
+                         hipEvent_t scan_done = nullptr) {
+    const int GR = group_rows_for(h, h->n_rows);
+    const int64_t n_super = (h->n_rows + kSuperRows - 1) / kSuperRows;
+    const int64_t n_groups = n_super * (kSuperRows / GR);  // group maxima per query (tail groups hold -inf)
     const int Gmax = max_groups_for_dim(h);
     const int chunk_q = 16 * Gmax;
     const size_t qfrag_bytes = (size_t)Gmax * h->KT * 1024;
@@ -322,8 +358,8 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     HIP_TRY(h, ws->gmax.ensure((size_t)B * n_groups * sizeof(float)));
     HIP_TRY(h, ws->cand.ensure((size_t)B * C * sizeof(int32_t)));
     HIP_TRY(h, ws->acut.ensure((size_t)B * sizeof(float)));
-    HIP_TRY(h, ws->cscore.ensure((size_t)B * C * kGroupRows * sizeof(float)));
-    HIP_TRY(h, ws->crow.ensure((size_t)B * C * kGroupRows * sizeof(int32_t)));
+    HIP_TRY(h, ws->cscore.ensure((size_t)B * C * GR * sizeof(float)));
+    HIP_TRY(h, ws->crow.ensure((size_t)B * C * GR * sizeof(int32_t)));
 
     for (int c0 = 0; c0 < B; c0 += chunk_q) {
         const int nq = std::min(chunk_q, B - c0);
@@ -344,11 +380,12 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
             Span sp(h, s, PH_SCAN);
             float* gm = ws->gmax.as<float>() + (int64_t)c0 * n_groups;
             hipError_t e = (h->dtype == HR_F16)
-                               ? launch_scan_g<_Float16>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_groups)
-                               : launch_scan_g<float>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_groups);
+                               ? launch_scan_g<_Float16>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
+                               : launch_scan_g<float>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
             HIP_TRY(h, e);
         }
     }
+    if (scan_done) HIP_TRY(h, hipEventRecord(scan_done, s));
     {
         Span sp(h, s, PH_GSEL);
         HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
@@ -357,15 +394,15 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
         Span sp(h, s, PH_REFINE);
         const int cosine = h->metric == HR_METRIC_COSINE;
         if (h->dtype == HR_F16)
-            hipLaunchKernelGGL((refine_dense_kernel<_Float16>), dim3(C, B), dim3(64), 0, s, h->tiles.as<chunk_t>(),
-                               h->KT, (int)h->dim, d_q, ws->qn2.as<double>(), h->norm2.as<double>(), d_mask,
-                               ws->cand.as<int32_t>(), C, h->n_rows, cosine, ws->cscore.as<float>(),
-                               ws->crow.as<int32_t>());
+            hipLaunchKernelGGL((refine_dense_kernel<_Float16>), dim3((C * GR + 63) / 64, B), dim3(64), 0, s,
+                               h->tiles.as<chunk_t>(), h->KT, (int)h->dim, d_q, ws->qn2.as<double>(),
+                               h->norm2.as<double>(), d_mask, ws->cand.as<int32_t>(), C, GR, h->n_rows, cosine,
+                               ws->cscore.as<float>(), ws->crow.as<int32_t>());
         else
-            hipLaunchKernelGGL((refine_dense_kernel<float>), dim3(C, B), dim3(64), 0, s, h->tiles.as<chunk_t>(),
-                               h->KT, (int)h->dim, d_q, ws->qn2.as<double>(), h->norm2.as<double>(), d_mask,
-                               ws->cand.as<int32_t>(), C, h->n_rows, cosine, ws->cscore.as<float>(),
-                               ws->crow.as<int32_t>());
+            hipLaunchKernelGGL((refine_dense_kernel<float>), dim3((C * GR + 63) / 64, B), dim3(64), 0, s,
+                               h->tiles.as<chunk_t>(), h->KT, (int)h->dim, d_q, ws->qn2.as<double>(),
+                               h->norm2.as<double>(), d_mask, ws->cand.as<int32_t>(), C, GR, h->n_rows, cosine,
+                               ws->cscore.as<float>(), ws->crow.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
     }
     {
@@ -374,7 +411,7 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
         int norm_mode;
         dense_eps(h, &eps_abs, &norm_mode);
         hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, s, ws->cscore.as<float>(),
-                           ws->crow.as<int32_t>(), C * kGroupRows, k, h->row_offset, ws->acut.as<float>(),
+                           ws->crow.as<int32_t>(), C * GR, k, h->row_offset, ws->acut.as<float>(),
                            -INFINITY, eps_abs, (const float*)nullptr, 0.0f, norm_mode, ws->qn2.as<double>(), d_ids,
                            d_scores, d_flags);
         HIP_TRY(h, hipGetLastError());
@@ -385,12 +422,13 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
 int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64_t* d_qptr, const int32_t* d_qidx,
                           const float* d_qval, int B, int max_q_nnz, int k, const uint8_t* d_mask, int64_t* d_ids,
                           float* d_scores, int32_t* d_flags, int C) {
-    const int64_t n_groups = (h->n_sparse + kGroupRows - 1) / kGroupRows;
+    const int GR = group_rows_for(h, h->n_sparse);
+    const int64_t n_groups = (h->n_sparse + GR - 1) / GR;
     HIP_TRY(h, ws->gmax.ensure((size_t)B * n_groups * sizeof(float)));
     HIP_TRY(h, ws->cand.ensure((size_t)B * C * sizeof(int32_t)));
     HIP_TRY(h, ws->acut.ensure((size_t)B * sizeof(float)));
-    HIP_TRY(h, ws->cscore.ensure((size_t)B * C * kGroupRows * sizeof(float)));
-    HIP_TRY(h, ws->crow.ensure((size_t)B * C * kGroupRows * sizeof(int32_t)));
+    HIP_TRY(h, ws->cscore.ensure((size_t)B * C * GR * sizeof(float)));
+    HIP_TRY(h, ws->crow.ensure((size_t)B * C * GR * sizeof(int32_t)));
     HIP_TRY(h, ws->qscale.ensure((size_t)B * sizeof(float)));
     HIP_TRY(h, ws->qeps.ensure((size_t)B * sizeof(float)));
     const int64_t V1 = h->sparse_dim + 1;
@@ -403,7 +441,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(1024), 0, s,
                            h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(),
                            h->post_doc.as<uint16_t>(), h->post_val.as<float>(), d_qptr + q0, d_qidx, d_qval,
-                           ws->qscale.as<float>() + q0, d_mask, h->n_sparse, n_groups,
+                           ws->qscale.as<float>() + q0, d_mask, h->n_sparse, n_groups, GR,
                            ws->gmax.as<float>() + (int64_t)q0 * n_groups);
         HIP_TRY(h, hipGetLastError());
     }
@@ -413,9 +451,10 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     }
     {
         Span sp(h, s, PH_SREFINE);
-        hipLaunchKernelGGL(refine_sparse_kernel, dim3((C + 3) / 4, B), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
-                           h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
-                           ws->cand.as<int32_t>(), C, h->n_sparse, ws->cscore.as<float>(), ws->crow.as<int32_t>());
+        hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 255) / 256, B), dim3(256), 0, s,
+                           h->s_indptr.as<int64_t>(), h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx,
+                           d_qval, d_mask, ws->cand.as<int32_t>(), C, GR, h->n_sparse, ws->cscore.as<float>(),
+                           ws->crow.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
     }
     {
@@ -426,7 +465,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         (void)max_q_nnz;
         const float eps_rel = (float)std::ldexp(1.0, -22);
         hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, s, ws->cscore.as<float>(),
-                           ws->crow.as<int32_t>(), C * kGroupRows, k, h->row_offset, ws->acut.as<float>(), 0.0f, 0.0f,
+                           ws->crow.as<int32_t>(), C * GR, k, h->row_offset, ws->acut.as<float>(), 0.0f, 0.0f,
                            ws->qeps.as<float>(), eps_rel, 0, (const double*)nullptr, d_ids, d_scores, d_flags);
         HIP_TRY(h, hipGetLastError());
     }
@@ -458,8 +497,8 @@ int fill_empty(hr_index* h, hipStream_t s, int B, int k, int64_t* d_ids, float* 
 
 int grow_dense(hr_index* h, int64_t need_rows) {
     if (need_rows <= h->cap_rows) return HR_OK;
-    int64_t new_cap = std::max<int64_t>(round_up(need_rows, kGroupRows),
-                                        round_up(h->cap_rows + h->cap_rows / 2, kGroupRows));
+    int64_t new_cap = std::max<int64_t>(round_up(need_rows, kSuperRows),
+                                        round_up(h->cap_rows + h->cap_rows / 2, kSuperRows));
     new_cap = std::max<int64_t>(new_cap, 1024);
     DevBuf nt, ns, nn;
     const size_t tb = tile_bytes_for_rows(h, new_cap);
@@ -629,6 +668,10 @@ int hr_create(int device, int64_t dim, int dtype, int metric, int64_t sparse_dim
         const int tile_elems = 4 * elems_per_chunk(dtype);
         h->KT = (int)round_up((dim + tile_elems - 1) / tile_elems, 4);  // multiple of the scan's prefetch depth
     }
+    if (const char* gr = std::getenv("HBMRAG_GROUP_ROWS")) {
+        const int v = std::atoi(gr);
+        if (v == 16 || v == 64) h->group_rows_override = v;
+    }
     DeviceGuard dg(device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->cu_count = prop.multiProcessorCount;
@@ -674,13 +717,13 @@ int hr_reserve(hr_index* h, int64_t n_rows) {
     DeviceGuard dg(h->device);
     if (n_rows <= h->cap_rows) return HR_OK;
     // exact-size allocation: temporarily defeat the 1.5x growth policy
-    const int64_t want = round_up(n_rows, kGroupRows);
+    const int64_t want = round_up(n_rows, kSuperRows);
     const int64_t saved = h->cap_rows;
     if (saved == 0) {
         h->cap_rows = 0;
         DevBuf nt, ns, nn;
-        const size_t tb = tile_bytes_for_rows(h, std::max<int64_t>(want, kGroupRows));
-        const int64_t rows = std::max<int64_t>(want, kGroupRows);
+        const size_t tb = tile_bytes_for_rows(h, std::max<int64_t>(want, kSuperRows));
+        const int64_t rows = std::max<int64_t>(want, kSuperRows);
         if (hipMalloc(&nt.p, tb) != hipSuccess || hipMalloc(&ns.p, (size_t)rows * 4) != hipSuccess ||
             hipMalloc(&nn.p, (size_t)rows * 8) != hipSuccess) {
             (void)hipGetLastError();
@@ -831,6 +874,49 @@ int hr_search_sparse_dev(hr_index* h, const int64_t* d_q_indptr, const int32_t* 
                                  d_flags, candidate_groups_for_k(k));
 }
 
+int hr_search_hybrid_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                         const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
+                         const uint8_t* d_rowmask, int64_t* d_ids, float* d_scores, int32_t* d_flags, void* stream) {
+    HR_TRY(check_search_args(h, B, k, true));
+    HR_TRY(check_search_args(h, B, k, false));
+    if (!d_q || !d_q_indptr || !d_ids || !d_scores || (q_nnz_total > 0 && (!d_q_idx || !d_q_val)))
+        return fail(h, HR_EINVAL, "null buffer");
+    if (max_q_nnz < 0 || max_q_nnz > HR_MAX_QUERY_NNZ) return fail(h, HR_ELIMIT, "query nnz exceeds HR_MAX_QUERY_NNZ");
+    std::shared_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    int64_t* s_ids = d_ids + (size_t)B * k;
+    float* s_scores = d_scores + (size_t)B * k;
+    int32_t* s_flags = d_flags ? d_flags + B : nullptr;
+    Workspace* ws = ws_for_stream(h, stream);
+    if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
+    if (!ws->side) {
+        HIP_TRY(h, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+        HIP_TRY(h, hipEventCreateWithFlags(&ws->ev_scan, hipEventDisableTiming));
+        HIP_TRY(h, hipEventCreateWithFlags(&ws->ev_side, hipEventDisableTiming));
+        ws->sparse_ws = new (std::nothrow) Workspace();
+        if (!ws->sparse_ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
+    }
+    const int C = candidate_groups_for_k(k);
+    if (h->n_rows == 0) {
+        HR_TRY(fill_empty(h, s, B, k, d_ids, d_scores, d_flags));
+        HIP_TRY(h, hipEventRecord(ws->ev_scan, s));
+    } else {
+        HR_TRY(dense_search_enqueue(h, ws, s, d_q, B, k, d_rowmask, d_ids, d_scores, d_flags, C, ws->ev_scan));
+    }
+    // sparse chain: starts when the dense scan is done, overlaps the dense tail
+    HIP_TRY(h, hipStreamWaitEvent(ws->side, ws->ev_scan, 0));
+    if (h->n_sparse == 0) {
+        HR_TRY(fill_empty(h, ws->side, B, k, s_ids, s_scores, s_flags));
+    } else {
+        HR_TRY(sparse_search_enqueue(h, ws->sparse_ws, ws->side, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k,
+                                     d_rowmask, s_ids, s_scores, s_flags, C));
+    }
+    HIP_TRY(h, hipEventRecord(ws->ev_side, ws->side));
+    HIP_TRY(h, hipStreamWaitEvent(s, ws->ev_side, 0));
+    return HR_OK;
+}
+
 int hr_fuse_rrf_dev(const int64_t* d_ids_a, int ka, const int64_t* d_ids_b, int kb, const int64_t* d_ids_c, int kc,
                     int B, double wa, double wb, double wc, int rrf_k, int top_k, int64_t* d_out_ids,
                     double* d_out_scores, int32_t* d_out_methods, int32_t* d_n_out, void* stream) {
@@ -902,7 +988,7 @@ int hr_search_dense(hr_index* h, const float* q, int B, int k, const uint8_t* ro
         HIP_TRY(h, hipMemcpyAsync(ws->d_mask.p, rowmask, mb, hipMemcpyHostToDevice, s));
         d_mask = ws->d_mask.as<uint8_t>();
     }
-    const int64_t n_groups = (h->n_rows + kGroupRows - 1) / kGroupRows;
+    const int64_t n_groups = (h->n_rows + group_rows_for(h, h->n_rows) - 1) / group_rows_for(h, h->n_rows);
     int C = candidate_groups_for_k(k);
     std::vector<int32_t> flags(B);
     for (;;) {
@@ -990,7 +1076,7 @@ int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx,
         HIP_TRY(h, hipMemcpyAsync(ws->d_mask.p, rowmask, mb, hipMemcpyHostToDevice, s));
         d_mask = ws->d_mask.as<uint8_t>();
     }
-    const int64_t n_groups = (h->n_sparse + kGroupRows - 1) / kGroupRows;
+    const int64_t n_groups = (h->n_sparse + group_rows_for(h, h->n_sparse) - 1) / group_rows_for(h, h->n_sparse);
     int C = candidate_groups_for_k(k);
     std::vector<int32_t> flags(B);
     for (;;) {

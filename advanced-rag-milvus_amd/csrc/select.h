@@ -19,48 +19,78 @@ struct SelectScratch {
     int count;
 };
 
+// One 8-bit radix pass: histogram of digit `shift` over the keys that match
+// (prefix, mask), then wave 0 finds the digit holding the `remaining`-th largest
+// (4 bins per lane + a wave scan instead of a serial walk over 256 bins).
+template <typename KeyFn>
+__device__ inline void radix_pass(KeyFn key, int64_t n, uint64_t prefix, uint64_t mask, int shift, int remaining,
+                                  SelectScratch& sh) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) sh.hist[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t kk = key(i);
+        if ((kk & mask) == prefix) atomicAdd(&sh.hist[(kk >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        // lane l owns bins 255-4l .. 252-4l (descending), so an inclusive scan over
+        // lanes is the count of keys in all higher bins.
+        const int lane = threadIdx.x;
+        const int top = 255 - 4 * lane;
+        const int c0 = (int)sh.hist[top], c1 = (int)sh.hist[top - 1], c2 = (int)sh.hist[top - 2],
+                  c3 = (int)sh.hist[top - 3];
+        const int mine = c0 + c1 + c2 + c3;
+        int incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
+        }
+        const int before = incl - mine;  // keys in bins above this lane's
+        if (before < remaining && incl >= remaining) {  // exactly one lane
+            int cum = before, d = top, cd = c0;
+            if (cum + c0 >= remaining) { d = top; cd = c0; }
+            else if ((cum += c0) + c1 >= remaining) { d = top - 1; cd = c1; }
+            else if ((cum += c1) + c2 >= remaining) { d = top - 2; cd = c2; }
+            else { cum += c2; d = top - 3; cd = c3; }
+            sh.digit = d;
+            sh.remaining = remaining - cum;
+            sh.count = cd;  // keys sharing the chosen digit (1 => the prefix already pins the key)
+        }
+    }
+    __syncthreads();
+}
+
 // K-th largest of n keys given by key(i), all threads of the block take part.
-// Keys must be unique except for the invalid key 0.  Requires 1 <= K <= n.
-// 8 passes of 8 bits; the 256-bin suffix scan of each pass is done by wave 0
-// (4 bins per lane + a wave scan) instead of a serial walk.
+// Keys are (ordered score << 32) | (~index): unique except for the invalid key 0.
+// Requires 1 <= K <= n.  Four passes resolve the score; when exactly one key
+// carries that score (the usual case) it is fetched directly, otherwise four
+// more passes resolve the index bits among the ties.
 template <typename KeyFn>
 __device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, SelectScratch& sh) {
     uint64_t prefix = 0, mask = 0;
     int remaining = K;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) sh.hist[i] = 0;
+    int same = 0;
+    for (int shift = 56; shift >= 32; shift -= 8) {
+        radix_pass(key, n, prefix, mask, shift, remaining, sh);
+        prefix |= (uint64_t)sh.digit << shift;
+        mask |= 0xFFull << shift;
+        remaining = sh.remaining;
+        same = sh.count;
         __syncthreads();
+    }
+    if (same == 1) {  // a single key has this score: find it
         for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-            uint64_t kk = key(i);
-            if ((kk & mask) == prefix) atomicAdd(&sh.hist[(kk >> shift) & 255], 1u);
+            const uint64_t kk = key(i);
+            if ((kk & mask) == prefix) sh.hist[0] = (unsigned int)(kk & 0xFFFFFFFFull);
         }
         __syncthreads();
-        if (threadIdx.x < 64) {
-            // lane l owns bins 255-4l .. 252-4l (descending), so an inclusive scan over
-            // lanes is the count of keys in all higher bins.
-            const int lane = threadIdx.x;
-            const int top = 255 - 4 * lane;
-            const int c0 = (int)sh.hist[top], c1 = (int)sh.hist[top - 1], c2 = (int)sh.hist[top - 2],
-                      c3 = (int)sh.hist[top - 3];
-            const int mine = c0 + c1 + c2 + c3;
-            int incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                int y = __shfl_up(incl, off);
-                if (lane >= off) incl += y;
-            }
-            const int before = incl - mine;  // keys in bins above this lane's
-            if (before < remaining && incl >= remaining) {  // exactly one lane
-                int cum = before, d = top;
-                if (cum + c0 >= remaining) d = top;
-                else if ((cum += c0) + c1 >= remaining) d = top - 1;
-                else if ((cum += c1) + c2 >= remaining) d = top - 2;
-                else { cum += c2; d = top - 3; }
-                sh.digit = d;
-                sh.remaining = remaining - cum;
-            }
-        }
+        prefix |= (uint64_t)sh.hist[0];
         __syncthreads();
+        return prefix;
+    }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        radix_pass(key, n, prefix, mask, shift, remaining, sh);
         prefix |= (uint64_t)sh.digit << shift;
         mask |= 0xFFull << shift;
         remaining = sh.remaining;

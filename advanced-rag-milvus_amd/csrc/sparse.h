@@ -11,7 +11,6 @@
 namespace hbmrag {
 
 constexpr int kRangeDocs = 16384;                     // docs per range = LDS accumulator length (u16 local ids)
-constexpr int kRangeGroups = kRangeDocs / kGroupRows;  // 256 candidate groups per range
 constexpr int kScanTermChunk = 256;                   // query terms staged per pass
 
 // ---- build: CSR (doc-major) -> range-major postings ---------------------------
@@ -128,17 +127,17 @@ __device__ inline int fixed_contrib(float p) {  // round away from zero, branch-
     const int a = __float2int_ru(fabsf(p));
     return p < 0.f ? -a : a;
 }
-// Accumulator index with one pad word per 64 docs: the per-group maxima then
-// read 64 different banks instead of one.
-__device__ inline int acc_index(int d) { return d + (d >> 6); }
+// Accumulator index with one pad word per 16 docs: the per-group maxima (one
+// thread per 16 docs, stride 17 words) then read conflict-free.
+__device__ inline int acc_index(int d) { return d + (d >> 4); }
 
 __global__ __launch_bounds__(1024) void sparse_scan_kernel(
     const unsigned int* __restrict__ rt_off, int64_t V1, const int64_t* __restrict__ range_base,
     const uint16_t* __restrict__ post_doc, const float* __restrict__ post_val,
     const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
     const float* __restrict__ q_val, const float* __restrict__ q_scale, const uint8_t* __restrict__ rowmask,
-    int64_t n_docs, int64_t n_groups, float* __restrict__ gmax) {
-    __shared__ int acc[kRangeDocs + kRangeDocs / 64];
+    int64_t n_docs, int64_t n_groups, int group_docs, float* __restrict__ gmax) {
+    __shared__ int acc[kRangeDocs + kRangeDocs / 16];
     __shared__ uint8_t item_run[kItemTable];
     __shared__ unsigned int run_lo[kScanTermChunk], run_hi[kScanTermChunk];
     __shared__ unsigned int item_pre[kScanTermChunk + 1];  // exclusive prefix of items per run
@@ -149,7 +148,7 @@ __global__ __launch_bounds__(1024) void sparse_scan_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     {
         int4* a4 = reinterpret_cast<int4*>(acc);
-        for (int i = tid; i < (kRangeDocs + kRangeDocs / 64) / 4; i += 1024) a4[i] = make_int4(0, 0, 0, 0);
+        for (int i = tid; i < (kRangeDocs + kRangeDocs / 16) / 4; i += 1024) a4[i] = make_int4(0, 0, 0, 0);
     }
     const unsigned int* offs = rt_off + range * V1;
     const uint16_t* pd = post_doc + range_base[range];
@@ -232,29 +231,34 @@ __global__ __launch_bounds__(1024) void sparse_scan_kernel(
         }
     }
     __syncthreads();
-    // per-group maxima: 256 groups, 4 threads per group
+    // per-group maxima: every thread reduces 16 consecutive docs; 64-doc groups
+    // finish with a 4-lane reduction
     {
-        const int grp = tid >> 2, sub = tid & 3;
         int m = 0;
-        const int64_t doc0 = range * kRangeDocs + grp * kGroupRows;
+        const int64_t doc0 = range * kRangeDocs + (int64_t)tid * 16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int local = j * 4 + sub;
-            int v = acc[acc_index(grp * kGroupRows + local)];
+            int v = acc[acc_index(tid * 16 + j)];
             if (rowmask) {
-                const int64_t dd = doc0 + local;
+                const int64_t dd = doc0 + j;
                 if (dd < n_docs && !((rowmask[dd >> 3] >> (dd & 7)) & 1)) v = 0;
             }
             m = max(m, v);
         }
-        m = max(m, __shfl_xor(m, 1));
-        m = max(m, __shfl_xor(m, 2));
-        const int64_t group = range * kRangeGroups + grp;
-        if (sub == 0 && group < n_groups) gmax[(int64_t)qi * n_groups + group] = scale > 0.f ? (float)m / scale : 0.f;
+        const float inv = scale > 0.f ? 1.0f / scale : 0.f;
+        if (group_docs == 16) {
+            const int64_t group = range * (kRangeDocs / 16) + tid;
+            if (group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)m * inv;
+        } else {
+            m = max(m, __shfl_xor(m, 1));
+            m = max(m, __shfl_xor(m, 2));
+            const int64_t group = range * (kRangeDocs / 64) + (tid >> 2);
+            if ((tid & 3) == 0 && group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)m * inv;
+        }
     }
 }
 
-// ---- refine: one wave per (query, candidate group); lane = doc -------------------
+// ---- refine: one thread per candidate doc (group_docs = 16 or 64 docs per group) ----
 // Canonical score: walk the doc's CSR entries in stored order, look each index
 // up in the query's sorted terms, accumulate exact products in fp64.
 // Restated in oracle/oracle.c:oracle_sparse_scores().
@@ -267,13 +271,12 @@ __global__ __launch_bounds__(256) void refine_sparse_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
     const float* __restrict__ q_val, const uint8_t* __restrict__ rowmask,
-    const int32_t* __restrict__ cand, int C, int64_t n_docs, float* __restrict__ out_score,
+    const int32_t* __restrict__ cand, int C, int group_docs, int64_t n_docs, float* __restrict__ out_score,
     int32_t* __restrict__ out_row) {
     __shared__ int32_t s_idx[HR_MAX_QUERY_NNZ];
     __shared__ float s_val[HR_MAX_QUERY_NNZ];
     __shared__ unsigned int s_filter[kFilterBits / 32];
-    const int qi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const int ci = blockIdx.x * 4 + (tid >> 6);
+    const int qi = blockIdx.y, tid = threadIdx.x;
     const int64_t t0 = q_indptr[qi];
     const int nt = min((int)(q_indptr[qi + 1] - t0), HR_MAX_QUERY_NNZ);
     for (int i = tid; i < kFilterBits / 32; i += 256) s_filter[i] = 0u;
@@ -285,25 +288,36 @@ __global__ __launch_bounds__(256) void refine_sparse_kernel(
         atomicOr(&s_filter[(t & (kFilterBits - 1)) >> 5], 1u << (t & 31));
     }
     __syncthreads();
-    if (ci >= C) return;
-    const int32_t group = cand[(int64_t)qi * C + ci];
-    const int64_t o = ((int64_t)qi * C + ci) * kGroupRows + lane;
-    const int64_t doc = (int64_t)group * kGroupRows + lane;
+    const int slot = blockIdx.x * 256 + tid;  // candidate doc slot of this query
+    const int n_slots = C * group_docs;
+    if (slot >= n_slots) return;
+    const int32_t group = cand[(int64_t)qi * C + slot / group_docs];
+    const int64_t o = (int64_t)qi * n_slots + slot;
+    const int64_t doc = (int64_t)group * group_docs + slot % group_docs;
     bool valid = group >= 0 && doc < n_docs;
     if (valid && rowmask) valid = (rowmask[doc >> 3] >> (doc & 7)) & 1;
     float score = 0.f;
     if (valid) {
         double s = 0.0;
         const int64_t e1 = indptr[doc + 1];
-        for (int64_t e = indptr[doc]; e < e1; ++e) {
-            const int32_t t = idx[e];
-            if (!((s_filter[(t & (kFilterBits - 1)) >> 5] >> (t & 31)) & 1u)) continue;
-            int lo = 0, hi = nt;  // first position with s_idx[pos] >= t
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_idx[mid] < t) lo = mid + 1; else hi = mid;
+        constexpr int U = 8;  // entries fetched per round trip
+        for (int64_t e = indptr[doc]; e < e1; e += U) {
+            int32_t t[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) t[u] = (e + u < e1) ? idx[e + u] : -1;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int32_t tt = t[u];
+                if (tt < 0) continue;
+                if (!((s_filter[(tt & (kFilterBits - 1)) >> 5] >> (tt & 31)) & 1u)) continue;
+                int lo = 0, hi = nt;  // first position with s_idx[pos] >= tt
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_idx[mid] < tt) lo = mid + 1; else hi = mid;
+                }
+                if (lo < nt && s_idx[lo] == tt)
+                    s = __dadd_rn(s, __dmul_rn((double)val[e + u], (double)s_val[lo]));
             }
-            if (lo < nt && s_idx[lo] == t) s = __dadd_rn(s, __dmul_rn((double)val[e], (double)s_val[lo]));
         }
         score = (float)s;
     }

@@ -152,6 +152,16 @@ HR_API int hr_search_sparse_dev(hr_index* h, const int64_t* d_q_indptr, const in
                          const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
                          const uint8_t* d_rowmask, int64_t* d_ids, float* d_scores,
                          int32_t* d_flags, void* stream);
+/* Both modalities of one query batch in ONE call: the dense scan runs alone on
+ * `stream`; the sparse chain then runs on a library-owned side stream so that
+ * it overlaps the dense path's latency-bound tail (candidate select, refine,
+ * top-k); `stream` waits for both before the call's work is considered done.
+ * Results are identical to calling the two *_dev forms one after the other.
+ * d_ids/d_scores/d_flags: dense lists first, then sparse ([2][B][k], [2][B]). */
+HR_API int hr_search_hybrid_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                         const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
+                         const uint8_t* d_rowmask, int64_t* d_ids, float* d_scores, int32_t* d_flags,
+                         void* stream);
 /* Batched RRF: lists are [B][ka], [B][kb], [B][kc] (kc = 0 / NULL for none);
  * outputs [B][top_k] ids / fp64 scores / method bitmasks and d_n_out[B]. */
 HR_API int hr_fuse_rrf_dev(const int64_t* d_ids_a, int ka, const int64_t* d_ids_b, int kb,
