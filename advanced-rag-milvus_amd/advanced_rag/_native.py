@@ -68,6 +68,11 @@ _SIGNATURES = {
     "hr_search_hybrid_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
                                         _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                         _c.c_void_p, _c.c_void_p]),
+    "hr_hybrid_scan_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
+                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p]),
+    "hr_hybrid_finish_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
+                                        _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                        _c.c_void_p, _c.c_void_p]),
     "hr_fuse_rrf_dev": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int,
                                    _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_int, _c.c_void_p,
                                    _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
@@ -266,6 +271,21 @@ class ShardHandle:
                                                    _vp(d_val) if d_val else None, B, nnz_total, max_q_nnz, k,
                                                    _vp(d_rowmask) if d_rowmask else None, _vp(d_ids), _vp(d_scores),
                                                    _vp(d_flags) if d_flags else None, _vp(stream) if stream else None))
+
+    def hybrid_scan_dev(self, d_q: int, d_indptr: int, d_idx: int, d_val: int, B: int, nnz_total: int, max_q_nnz: int,
+                        k: int, slot: int, stream: int = 0, d_rowmask: int = 0):
+        self._check(self._lib.hr_hybrid_scan_dev(self._h, _vp(d_q), _vp(d_indptr), _vp(d_idx) if d_idx else None,
+                                                 _vp(d_val) if d_val else None, B, nnz_total, max_q_nnz, k,
+                                                 _vp(d_rowmask) if d_rowmask else None, slot,
+                                                 _vp(stream) if stream else None))
+
+    def hybrid_finish_dev(self, d_q: int, d_indptr: int, d_idx: int, d_val: int, B: int, max_q_nnz: int, k: int,
+                          slot: int, d_ids: int, d_scores: int, d_flags: int = 0, stream: int = 0, d_rowmask: int = 0):
+        self._check(self._lib.hr_hybrid_finish_dev(self._h, _vp(d_q), _vp(d_indptr), _vp(d_idx) if d_idx else None,
+                                                   _vp(d_val) if d_val else None, B, max_q_nnz, k,
+                                                   _vp(d_rowmask) if d_rowmask else None, slot, _vp(d_ids),
+                                                   _vp(d_scores), _vp(d_flags) if d_flags else None,
+                                                   _vp(stream) if stream else None))
 
     # -- measurement
     def set_profiling(self, level: int):

@@ -199,6 +199,11 @@ class HybridSearchEngine:
         else:
             self.h.search_dense_dev(q.data_ptr(), B, kp, b["ids"][0].data_ptr(), b["scores"][0].data_ptr(),
                                     b["flags"][0].data_ptr(), 0, stream)
+        return self._post_lists(b, B, stream)
+
+    def _post_lists(self, b: dict, B: int, stream: int) -> dict:
+        """Everything after the per-shard lists exist: [exchange + merge] -> RRF -> rerank."""
+        cfg, kp = self.cfg, b["kp"]
         ids, scores = b["ids"], b["scores"]
         if self.world > 1:
             g = exchange_lists(b["pack"], self.world, self.dist, self.group, out=b["gathered"])
@@ -225,3 +230,72 @@ class HybridSearchEngine:
         indptr, idx, val, max_nnz = packed
         return (t.from_numpy(indptr).to(self.device), t.from_numpy(idx).to(self.device),
                 t.from_numpy(val).to(self.device), max_nnz)
+
+
+class PipelinedSearchEngine(HybridSearchEngine):
+    """Keeps `depth` query batches in flight on two HIP streams.
+
+    The bandwidth-bound scans of consecutive batches run back to back on the HEAVY stream
+    (hr_hybrid_scan_dev, one workspace slot per batch in flight); everything that follows a batch's
+    scans — candidate select, canonical refine, top-k, the RCCL exchange, merge, RRF, rerank — runs
+    on the LIGHT stream and so hides behind the next batch's scans.  Scans never overlap each
+    other, which keeps the event-timed scan (roofline) meaningful.  Results of `submit` are valid
+    once the light stream has passed the returned `done` event (or after `synchronize()`).
+    Requires the sparse modality (the two-phase C entry points are hybrid).
+    """
+
+    def __init__(self, handle, config: Optional[EngineConfig] = None, process_group=None, device: Optional[str] = None,
+                 depth: int = 2):
+        super().__init__(handle, config, process_group, device)
+        if not self.cfg.use_sparse:
+            raise ValueError("PipelinedSearchEngine needs the sparse modality")
+        if not 1 <= depth <= 4:
+            raise ValueError("depth must be 1..4 (HR_MAX_SLOTS)")
+        t = self.torch
+        self.depth = depth
+        self.heavy = t.cuda.Stream(self.device)
+        self.light = t.cuda.Stream(self.device)
+        self._slot_bufs = [dict() for _ in range(depth)]
+        self._n = 0
+
+    def _slot(self, slot: int, B: int) -> dict:
+        b = self._slot_bufs[slot].get(B)
+        if b is None:
+            self._bufs.pop(B, None)  # fresh buffer set for this slot
+            b = self._buffers(B)
+            self._bufs.pop(B, None)
+            t = self.torch
+            b["scan_done"] = t.cuda.Event()
+            b["done"] = t.cuda.Event()
+            b["done"].record(t.cuda.current_stream(self.device))
+            self._slot_bufs[slot][B] = b
+        return b
+
+    def submit(self, q, sparse) -> dict:
+        t, cfg = self.torch, self.cfg
+        B = q.shape[0]
+        slot = self._n % self.depth
+        self._n += 1
+        b = self._slot(slot, B)
+        kp = b["kp"]
+        indptr, idx, val, max_nnz = sparse
+        nnz = int(idx.shape[0])
+        self.heavy.wait_event(b["done"])  # the batch that used this slot before has been finished
+        self.h.hybrid_scan_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, nnz, int(max_nnz),
+                               kp, slot, self.heavy.cuda_stream)
+        b["scan_done"].record(self.heavy)
+        self.light.wait_event(b["scan_done"])
+        with t.cuda.stream(self.light):
+            self.h.hybrid_finish_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, int(max_nnz),
+                                     kp, slot, b["ids"].data_ptr(), b["scores"].data_ptr(), b["flags"].data_ptr(),
+                                     self.light.cuda_stream)
+            self._post_lists(b, B, self.light.cuda_stream)
+            b["done"].record(self.light)
+        return b
+
+    def synchronize(self):
+        self.heavy.synchronize()
+        self.light.synchronize()
+
+    def all_flags_exact(self) -> bool:
+        return all(bool(b["flags"].min().item() == 1) for slot in self._slot_bufs for b in slot.values())

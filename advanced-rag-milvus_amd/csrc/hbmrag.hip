@@ -123,6 +123,7 @@ struct hr_index {
     std::mutex pool_mu;
     std::vector<Workspace*> free_ws;
     std::map<void*, Workspace*> stream_ws;
+    Workspace* slot_ws[HR_MAX_SLOTS][2] = {};  // [slot][dense|sparse] of the two-phase forms
     std::mutex prof_mu;
     std::vector<EventSpan> spans;
     std::vector<hipEvent_t> event_pool;
@@ -344,9 +345,13 @@ void dense_eps(const hr_index* h, float* eps_abs, int* norm_mode) {
 }
 
 // Enqueue a complete dense search on stream s.  All pointers are device pointers.
+enum { PHASE_SCAN = 1, PHASE_FINISH = 2, PHASE_ALL = 3 };
+
+// Enqueue a dense search on stream s: PHASE_SCAN = query prep + the shard scan (leaves the group
+// maxima in ws), PHASE_FINISH = candidate select + refine + top-k from those maxima.
 int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float* d_q, int B, int k,
                          const uint8_t* d_mask, int64_t* d_ids, float* d_scores, int32_t* d_flags, int C,
-                         hipEvent_t scan_done = nullptr) {
+                         hipEvent_t scan_done = nullptr, int phases = PHASE_ALL) {
     const int GR = group_rows_for(h, h->n_rows);
     const int64_t n_super = (h->n_rows + kSuperRows - 1) / kSuperRows;
     const int64_t n_groups = n_super * (kSuperRows / GR);  // group maxima per query (tail groups hold -inf)
@@ -361,7 +366,7 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     HIP_TRY(h, ws->cscore.ensure((size_t)B * C * GR * sizeof(float)));
     HIP_TRY(h, ws->crow.ensure((size_t)B * C * GR * sizeof(int32_t)));
 
-    for (int c0 = 0; c0 < B; c0 += chunk_q) {
+    for (int c0 = 0; (phases & PHASE_SCAN) && c0 < B; c0 += chunk_q) {
         const int nq = std::min(chunk_q, B - c0);
         const int G = (nq + 15) / 16;
         {
@@ -386,6 +391,7 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
         }
     }
     if (scan_done) HIP_TRY(h, hipEventRecord(scan_done, s));
+    if (!(phases & PHASE_FINISH)) return HR_OK;
     {
         Span sp(h, s, PH_GSEL);
         HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
@@ -421,7 +427,7 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
 
 int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64_t* d_qptr, const int32_t* d_qidx,
                           const float* d_qval, int B, int max_q_nnz, int k, const uint8_t* d_mask, int64_t* d_ids,
-                          float* d_scores, int32_t* d_flags, int C) {
+                          float* d_scores, int32_t* d_flags, int C, int phases = PHASE_ALL) {
     const int GR = group_rows_for(h, h->n_sparse);
     const int64_t n_groups = (h->n_sparse + GR - 1) / GR;
     HIP_TRY(h, ws->gmax.ensure((size_t)B * n_groups * sizeof(float)));
@@ -432,10 +438,12 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     HIP_TRY(h, ws->qscale.ensure((size_t)B * sizeof(float)));
     HIP_TRY(h, ws->qeps.ensure((size_t)B * sizeof(float)));
     const int64_t V1 = h->sparse_dim + 1;
-    hipLaunchKernelGGL(sparse_query_prep_kernel, dim3(B), dim3(256), 0, s, d_qptr, d_qval, h->max_sparse_abs,
-                       ws->qscale.as<float>(), ws->qeps.as<float>());
-    HIP_TRY(h, hipGetLastError());
-    for (int q0 = 0; q0 < B; q0 += 32768) {  // gridDim.y limit
+    if (phases & PHASE_SCAN) {
+        hipLaunchKernelGGL(sparse_query_prep_kernel, dim3(B), dim3(256), 0, s, d_qptr, d_qval, h->max_sparse_abs,
+                           ws->qscale.as<float>(), ws->qeps.as<float>());
+        HIP_TRY(h, hipGetLastError());
+    }
+    for (int q0 = 0; (phases & PHASE_SCAN) && q0 < B; q0 += 32768) {  // gridDim.y limit
         const int nq = std::min(32768, B - q0);
         Span sp(h, s, PH_SSCAN);
         hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(1024), 0, s,
@@ -445,6 +453,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
                            ws->gmax.as<float>() + (int64_t)q0 * n_groups);
         HIP_TRY(h, hipGetLastError());
     }
+    if (!(phases & PHASE_FINISH)) return HR_OK;
     {
         Span sp(h, s, PH_SGSEL);
         HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
@@ -692,6 +701,9 @@ void hr_destroy(hr_index* h) {
         (void)hipDeviceSynchronize();
         for (Workspace* w : h->free_ws) { w->release(); delete w; }
         for (auto& kv : h->stream_ws) { kv.second->release(); delete kv.second; }
+        for (auto& pair : h->slot_ws)
+            for (Workspace* w : pair)
+                if (w) { w->release(); delete w; }
         for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
         for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
         for (DevBuf* b : {&h->tiles, &h->scale, &h->norm2, &h->max_norm, &h->stage, &h->s_indptr, &h->s_idx, &h->s_val,
@@ -914,6 +926,67 @@ int hr_search_hybrid_dev(hr_index* h, const float* d_q, const int64_t* d_q_indpt
     }
     HIP_TRY(h, hipEventRecord(ws->ev_side, ws->side));
     HIP_TRY(h, hipStreamWaitEvent(s, ws->ev_side, 0));
+    return HR_OK;
+}
+
+static int slot_workspaces(hr_index* h, int slot, Workspace** dense, Workspace** sparse) {
+    if (slot < 0 || slot >= HR_MAX_SLOTS) return fail(h, HR_EINVAL, "slot %d out of range [0,%d)", slot, HR_MAX_SLOTS);
+    std::lock_guard<std::mutex> g(h->pool_mu);
+    for (int m = 0; m < 2; ++m)
+        if (!h->slot_ws[slot][m]) {
+            h->slot_ws[slot][m] = new (std::nothrow) Workspace();
+            if (!h->slot_ws[slot][m]) return fail(h, HR_ENOMEM, "workspace allocation failed");
+        }
+    *dense = h->slot_ws[slot][0];
+    *sparse = h->slot_ws[slot][1];
+    return HR_OK;
+}
+
+int hr_hybrid_scan_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                       const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
+                       const uint8_t* d_rowmask, int slot, void* stream) {
+    HR_TRY(check_search_args(h, B, k, true));
+    HR_TRY(check_search_args(h, B, k, false));
+    if (!d_q || !d_q_indptr || (q_nnz_total > 0 && (!d_q_idx || !d_q_val))) return fail(h, HR_EINVAL, "null buffer");
+    if (max_q_nnz < 0 || max_q_nnz > HR_MAX_QUERY_NNZ) return fail(h, HR_ELIMIT, "query nnz exceeds HR_MAX_QUERY_NNZ");
+    std::shared_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    Workspace *wd, *wsp;
+    HR_TRY(slot_workspaces(h, slot, &wd, &wsp));
+    hipStream_t s = (hipStream_t)stream;
+    const int C = candidate_groups_for_k(k);
+    if (h->n_rows > 0)
+        HR_TRY(dense_search_enqueue(h, wd, s, d_q, B, k, d_rowmask, nullptr, nullptr, nullptr, C, nullptr, PHASE_SCAN));
+    if (h->n_sparse > 0)
+        HR_TRY(sparse_search_enqueue(h, wsp, s, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, nullptr,
+                                     nullptr, nullptr, C, PHASE_SCAN));
+    return HR_OK;
+}
+
+int hr_hybrid_finish_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                         const float* d_q_val, int B, int max_q_nnz, int k, const uint8_t* d_rowmask, int slot,
+                         int64_t* d_ids, float* d_scores, int32_t* d_flags, void* stream) {
+    HR_TRY(check_search_args(h, B, k, true));
+    HR_TRY(check_search_args(h, B, k, false));
+    if (!d_q || !d_q_indptr || !d_ids || !d_scores) return fail(h, HR_EINVAL, "null buffer");
+    std::shared_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    Workspace *wd, *wsp;
+    HR_TRY(slot_workspaces(h, slot, &wd, &wsp));
+    hipStream_t s = (hipStream_t)stream;
+    const int C = candidate_groups_for_k(k);
+    int64_t* s_ids = d_ids + (size_t)B * k;
+    float* s_scores = d_scores + (size_t)B * k;
+    int32_t* s_flags = d_flags ? d_flags + B : nullptr;
+    if (h->n_rows > 0)
+        HR_TRY(dense_search_enqueue(h, wd, s, d_q, B, k, d_rowmask, d_ids, d_scores, d_flags, C, nullptr, PHASE_FINISH));
+    else
+        HR_TRY(fill_empty(h, s, B, k, d_ids, d_scores, d_flags));
+    if (h->n_sparse > 0)
+        HR_TRY(sparse_search_enqueue(h, wsp, s, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, s_ids,
+                                     s_scores, s_flags, C, PHASE_FINISH));
+    else
+        HR_TRY(fill_empty(h, s, B, k, s_ids, s_scores, s_flags));
     return HR_OK;
 }
 

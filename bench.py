@@ -13,7 +13,11 @@ of the per-shard top-k' lists.  Rank 0 prints ONE JSON line.
 
 What is inside the timed region: K full steps (all kernels + collective) with
 queries already resident in HBM; nothing is cached between steps (each step
-uses a different query batch) and nothing is skipped.  The dense-scan kernel is
+uses a different query batch) and nothing is skipped.  By default two batches
+are in flight (--in-flight 2): the scans of batch i+1 run on a heavy stream
+while batch i is finished on a light stream — the way the reference's service
+overlaps up to 64 concurrent retrieve() calls (service.py:137,149); every step's
+results are complete when the region ends.  The dense-scan kernel is
 bracketed with HIP events on its own stream inside the timed region
 (hr_set_profiling(1)) to get roofline.achieved.  The CPU baseline (N=1 only) is
 the oracle's numpy/scipy restatement of the reference path timed on a 1M-row
@@ -56,6 +60,23 @@ def sparse_block(block: int, n: int, seed: int = 5678):
     return indptr, idx.reshape(-1), val.reshape(-1)
 
 
+def pmc_traffic(rows: int, dim: int, batch: int, n_gpus: int):
+    """HBM bytes per dense-scan launch from the committed PMC passes (profiles/r*_pmc_traffic.json:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, FETCH doubled as the
+    gfx950 guide prescribes).  Only returned when the profiled workload is the one being run."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            w = d.get("workload", {})
+            if n_gpus == 1 and (w.get("rows"), w.get("dim"), w.get("batch")) == (rows, dim, batch):
+                return d["kernels"]["dense_scan"]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
+
+
 def make_queries(n_batches: int, B: int, dim: int, seed: int = 4321):
     rng = np.random.default_rng(seed)
     Q = rng.standard_normal((n_batches, B, dim), dtype=np.float32)
@@ -83,13 +104,15 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel phase, not just the scans")
     ap.add_argument("--in-flight", type=int, default=2,
-                    help="query batches kept in flight (one engine + HIP stream each, round-robin)")
+                    help="query batches kept in flight: 1 = one batch at a time; 2..4 = scans of batch i+1 on a heavy "
+                         "stream while batch i is finished (select/refine/exchange/fuse) on a light stream")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from advanced_rag import _native as nat
-    from advanced_rag.engine import EngineConfig, HybridSearchEngine, pack_sparse_queries, shard_range
+    from advanced_rag.engine import (EngineConfig, HybridSearchEngine, PipelinedSearchEngine, pack_sparse_queries,
+                                     shard_range)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -163,10 +186,9 @@ def main():
     n_batches = 8
     Q, SQ = make_queries(n_batches, B, D)
     cfg = EngineConfig(top_k=args.top_k, use_sparse=use_sparse)
-    n_fly = max(1, args.in_flight)
-    engines = [HybridSearchEngine(h, cfg, device=str(dev), stream=torch.cuda.Stream(dev) if n_fly > 1 else None)
-               for _ in range(n_fly)]
-    eng = engines[0]
+    n_fly = max(1, args.in_flight) if use_sparse else 1
+    eng = PipelinedSearchEngine(h, cfg, device=str(dev), depth=n_fly) if n_fly > 1 else \
+        HybridSearchEngine(h, cfg, device=str(dev))
     dQ = [torch.from_numpy(Q[i]).to(dev) for i in range(n_batches)]
     dS = [eng.upload_sparse(pack_sparse_queries(SQ[i], 0.2)) if use_sparse else None for i in range(n_batches)]
     kp = 2 * args.top_k
@@ -205,7 +227,9 @@ def main():
 
     # ---- timed region -----------------------------------------------------------------------------------
     def step(i):
-        return engines[i % n_fly].search(dQ[i % n_batches], dS[i % n_batches])
+        if n_fly > 1:
+            return eng.submit(dQ[i % n_batches], dS[i % n_batches])
+        return eng.search(dQ[i % n_batches], dS[i % n_batches])
 
     for i in range(args.warmup):
         step(i)
@@ -229,7 +253,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     phases = h.kernel_ms()
-    flags_exact = all(bool(e._bufs[B]["flags"].min().item() == 1) for e in engines if B in e._bufs)
+    flags_exact = eng.all_flags_exact() if n_fly > 1 else bool(out["flags"].min().item() == 1)
     if world > 1:
         ft = torch.tensor([1 if flags_exact else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
         dist.all_reduce(ft, op=dist.ReduceOp.MIN)
@@ -238,6 +262,20 @@ def main():
     scan_ms, scan_launches = phases["dense_scan"]
     scan_bytes = h.dense_scan_bytes
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+
+    # Extra (outside the timed region): the same scan kernel with nothing else on the GPU, to show how
+    # much of the in-region figure is contention from the light stream of the batch in flight.
+    iso_ms = None
+    if rank == 0 or world > 1:
+        one = HybridSearchEngine(h, cfg, device=str(dev)) if n_fly > 1 else eng
+        h.set_profiling(1)
+        for i in range(5):
+            one.h.search_dense_dev(dQ[i % n_batches].data_ptr(), B, kp, one._buffers(B)["ids"][0].data_ptr(),
+                                   one._buffers(B)["scores"][0].data_ptr(), one._buffers(B)["flags"][0].data_ptr(), 0,
+                                   torch.cuda.current_stream(dev).cuda_stream)
+            torch.cuda.synchronize()
+        h.set_profiling(0)
+        iso_ms = h.kernel_ms()["dense_scan"][0]
 
     # ---- p50 latency of single-query retrieve() through the Python API (N=1) --------------------------------
     latency = None
@@ -273,6 +311,7 @@ def main():
                          f"first {n_s} rows x {B} queries, {reps} reps, time extrapolated x{N / n_s:.1f} to {N} rows"}
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic(N, D, B, world)
         total_q = B * args.steps
         res = {
             "metric": "queries_per_sec_hybrid_retrieve", "value": total_q / elapsed, "unit": "queries/s",
@@ -285,8 +324,11 @@ def main():
                        "batches_in_flight": n_fly,
                        "parallelism": f"row-sharded x{world}, one RCCL all-gather of per-shard top-k' per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "dense_scan_kernel<f16>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches},
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches,
+                         "isolated_launch_ms": iso_ms,
+                         "isolated_achieved": (scan_bytes / (iso_ms * 1e-3) / 1e9) if iso_ms else None},
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
             "all_lists_proven_exact": flags_exact,

@@ -162,6 +162,22 @@ HR_API int hr_search_hybrid_dev(hr_index* h, const float* d_q, const int64_t* d_
                          const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
                          const uint8_t* d_rowmask, int64_t* d_ids, float* d_scores, int32_t* d_flags,
                          void* stream);
+/* Two-phase form of the same search, for keeping several query batches in
+ * flight: phase 1 (`scan`) = query prep + the two bandwidth-bound shard scans,
+ * leaving the per-group maxima in workspace `slot` (0 <= slot < HR_MAX_SLOTS);
+ * phase 2 (`finish`) = candidate select + canonical refine + top-k for both
+ * modalities from that slot.  A caller alternates slots and puts the scans of
+ * batch i+1 on one stream while the finish of batch i (plus exchange, merge,
+ * fuse, rerank) runs on another — scans never overlap each other, the
+ * latency-bound tail hides behind them.  The caller orders the phases of one
+ * slot with events; `finish` takes the same query buffers as `scan`. */
+#define HR_MAX_SLOTS 4
+HR_API int hr_hybrid_scan_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                       const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
+                       const uint8_t* d_rowmask, int slot, void* stream);
+HR_API int hr_hybrid_finish_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                         const float* d_q_val, int B, int max_q_nnz, int k, const uint8_t* d_rowmask, int slot,
+                         int64_t* d_ids, float* d_scores, int32_t* d_flags, void* stream);
 /* Batched RRF: lists are [B][ka], [B][kb], [B][kc] (kc = 0 / NULL for none);
  * outputs [B][top_k] ids / fp64 scores / method bitmasks and d_n_out[B]. */
 HR_API int hr_fuse_rrf_dev(const int64_t* d_ids_a, int ka, const int64_t* d_ids_b, int kb,

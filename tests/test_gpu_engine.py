@@ -181,3 +181,41 @@ def test_index_manager_and_retriever_on_gpu(gpu):
     finally:
         RetrievalConstants.TIMEOUT_SECONDS = old
         asyncio.run(p.close())
+
+
+def test_pipelined_engine_matches_sequential(gpu):
+    """Two batches in flight (scans on the heavy stream, finish on the light stream) give the same
+    lists, fused results and rerank output as one batch at a time."""
+    from advanced_rag.engine import PipelinedSearchEngine
+    n, d, V, nnz, B = 30000, 128, 1000, 10, 16
+    X, ptr, idx, val, _, _ = corpus(n, d, V, nnz, B, seed=21)
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    h.add_dense(X)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    cfg = EngineConfig(top_k=20)
+    seq = HybridSearchEngine(h, cfg)
+    pipe = PipelinedSearchEngine(h, cfg, depth=2)
+    rng = np.random.default_rng(3)
+    batches = []
+    for _ in range(5):
+        Q = rng.standard_normal((B, d)).astype(np.float32)
+        SQ = [(np.sort(rng.choice(V, 30, replace=False)).astype(np.int32), np.abs(rng.standard_normal(30)).astype(np.float32))
+              for _ in range(B)]
+        batches.append((torch.from_numpy(Q).cuda(), seq.upload_sparse(pack_sparse_queries(SQ, 0.2))))
+    want = []
+    for q, sq in batches:
+        o = seq.search(q, sq)
+        torch.cuda.synchronize()
+        want.append({k: o[k].clone() for k in ("ids", "scores", "fused_ids", "fused_scores", "fused_methods", "rr_ids", "rr_scores")})
+    got = []
+    for q, sq in batches:  # submit everything without waiting; copy results out in stream order
+        o = pipe.submit(q, sq)
+        with torch.cuda.stream(pipe.light):
+            got.append({k: o[k].clone() for k in want[0]})
+    pipe.synchronize()
+    assert pipe.all_flags_exact()
+    for w, g in zip(want, got):
+        for k in w:
+            assert torch.equal(w[k], g[k]), k
+    h.close()
