@@ -1,0 +1,268 @@
+"""Sentence encoder and cross-encoder forward passes in PyTorch-ROCm.
+
+The reference leaves both as plugin hooks: `index_manager.embedding_generator.
+encode_semantic / encode_domain` (reference indexing.py:120, :610-620, :665-673)
+and `retriever.reranker.score(pairs)` via `CrossEncoderReranker.model.predict`
+(retrieval.py:546-547, :675-678; default name cross-encoder/ms-marco-MiniLM-L-6-v2).
+These classes fill the hooks with BERT/MiniLM-shaped transformers whose GEMMs run
+on the MFMA units through PyTorch (this is the one place the north star wants
+PyTorch-ROCm rather than hand-written HIP).
+
+Offline there are no weights: models are RANDOM-INIT with a fixed seed, so
+results are structurally valid (shapes, determinism, batching, dtype) but carry
+no semantics.  `load_local(path)` reads a local safetensors file with
+HuggingFace BERT parameter names when a caller has one; nothing is ever fetched
+by model name.
+"""
+from __future__ import annotations
+
+import math
+import re
+import zlib
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+_WORD = re.compile(r"\w+|[^\w\s]")
+PAD, CLS, SEP = 0, 101, 102
+
+
+@dataclass
+class EncoderConfig:
+    """MiniLM-L6-H384 shape by default (the class of model the reference names)."""
+    vocab_size: int = 30522
+    hidden: int = 384
+    layers: int = 6
+    heads: int = 12
+    intermediate: int = 1536
+    max_len: int = 512
+    type_vocab: int = 2
+    eps: float = 1e-12
+
+
+class HashTokenizer:
+    """Dependency-free stand-in for WordPiece: lower-cased words/punctuation hashed
+    (crc32) into the vocabulary.  Real vocabularies are not available offline."""
+
+    def __init__(self, vocab_size: int = 30522, max_len: int = 512):
+        self.vocab_size, self.max_len = vocab_size, max_len
+
+    def _ids(self, text: str) -> List[int]:
+        return [1000 + zlib.crc32(t.encode("utf-8")) % (self.vocab_size - 1000) for t in _WORD.findall(text.lower())]
+
+    def encode(self, text: str, pair: Optional[str] = None) -> Tuple[List[int], List[int]]:
+        a = self._ids(text)
+        if pair is None:
+            ids = [CLS] + a[: self.max_len - 2] + [SEP]
+            return ids, [0] * len(ids)
+        b = self._ids(pair)
+        room = self.max_len - 3
+        a = a[: max(1, min(len(a), room // 2))]
+        b = b[: room - len(a)]
+        ids = [CLS] + a + [SEP] + b + [SEP]
+        return ids, [0] * (len(a) + 2) + [1] * (len(b) + 1)
+
+    def batch(self, texts: Sequence[str], pairs: Optional[Sequence[str]] = None, device="cpu"):
+        enc = [self.encode(t, None if pairs is None else pairs[i]) for i, t in enumerate(texts)]
+        width = max(len(i) for i, _ in enc)
+        width = -(-width // 8) * 8  # friendlier GEMM shapes
+        ids = torch.full((len(enc), width), PAD, dtype=torch.long)
+        types = torch.zeros((len(enc), width), dtype=torch.long)
+        for r, (i, t) in enumerate(enc):
+            ids[r, : len(i)] = torch.tensor(i)
+            types[r, : len(t)] = torch.tensor(t)
+        return ids.to(device), types.to(device), (ids != PAD).to(device)
+
+
+class _Layer(nn.Module):
+    def __init__(self, c: EncoderConfig):
+        super().__init__()
+        self.heads = c.heads
+        self.qkv = nn.Linear(c.hidden, 3 * c.hidden)
+        self.out = nn.Linear(c.hidden, c.hidden)
+        self.ln1 = nn.LayerNorm(c.hidden, eps=c.eps)
+        self.up = nn.Linear(c.hidden, c.intermediate)
+        self.down = nn.Linear(c.intermediate, c.hidden)
+        self.ln2 = nn.LayerNorm(c.hidden, eps=c.eps)
+
+    def forward(self, x, attn_bias):
+        B, T, H = x.shape
+        q, k, v = self.qkv(x).view(B, T, 3, self.heads, H // self.heads).permute(2, 0, 3, 1, 4)
+        a = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias)
+        x = self.ln1(x + self.out(a.transpose(1, 2).reshape(B, T, H)))  # post-LN, as BERT
+        return self.ln2(x + self.down(F.gelu(self.up(x))))
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, config: Optional[EncoderConfig] = None):
+        super().__init__()
+        c = self.config = config or EncoderConfig()
+        self.word = nn.Embedding(c.vocab_size, c.hidden, padding_idx=PAD)
+        self.pos = nn.Embedding(c.max_len, c.hidden)
+        self.seg = nn.Embedding(c.type_vocab, c.hidden)
+        self.ln = nn.LayerNorm(c.hidden, eps=c.eps)
+        self.layers = nn.ModuleList(_Layer(c) for _ in range(c.layers))
+
+    def forward(self, ids, types, mask):
+        T = ids.shape[1]
+        x = self.ln(self.word(ids) + self.pos(torch.arange(T, device=ids.device))[None] + self.seg(types))
+        bias = torch.zeros(mask.shape, dtype=x.dtype, device=x.device).masked_fill(~mask, float("-inf"))[:, None, None, :]
+        for layer in self.layers:
+            x = layer(x, bias)
+        return x
+
+
+def _seeded(module_fn, seed: int):
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        m = module_fn()
+        for mod in m.modules():  # BERT init: N(0, 0.02)
+            if isinstance(mod, (nn.Linear, nn.Embedding)):
+                nn.init.normal_(mod.weight, std=0.02)
+            if isinstance(mod, nn.Linear) and mod.bias is not None:
+                nn.init.zeros_(mod.bias)
+        return m
+    finally:
+        torch.random.set_rng_state(gen_state)
+
+
+class _Base:
+    def __init__(self, config, device, dtype, seed, max_len, batch_size):
+        self.config = config or EncoderConfig()
+        self.device = torch.device(device if device is not None else ("cuda:0" if torch.cuda.is_available() else "cpu"))
+        self.dtype = dtype if dtype is not None else (torch.float16 if self.device.type == "cuda" else torch.float32)
+        self.tokenizer = HashTokenizer(self.config.vocab_size, min(max_len, self.config.max_len))
+        self.batch_size = batch_size
+        self.seed = seed
+
+    def load_local(self, path: str) -> "._Base":
+        """Load weights from a LOCAL safetensors file with HuggingFace BERT names (never by model name)."""
+        from safetensors.torch import load_file
+        sd = load_file(path)
+        own = self.module.state_dict()
+        mapped = {}
+        pre = "bert." if any(k.startswith("bert.") for k in sd) else ""
+        emb = pre + "embeddings."
+        for ours, theirs in (("encoder.word.weight", emb + "word_embeddings.weight"),
+                             ("encoder.pos.weight", emb + "position_embeddings.weight"),
+                             ("encoder.seg.weight", emb + "token_type_embeddings.weight"),
+                             ("encoder.ln.weight", emb + "LayerNorm.weight"), ("encoder.ln.bias", emb + "LayerNorm.bias")):
+            if theirs in sd:
+                mapped[ours] = sd[theirs]
+        for i in range(self.config.layers):
+            L = f"{pre}encoder.layer.{i}."
+            try:
+                mapped[f"encoder.layers.{i}.qkv.weight"] = torch.cat([sd[L + f"attention.self.{n}.weight"] for n in ("query", "key", "value")])
+                mapped[f"encoder.layers.{i}.qkv.bias"] = torch.cat([sd[L + f"attention.self.{n}.bias"] for n in ("query", "key", "value")])
+            except KeyError:
+                continue
+            for ours, theirs in (("out", "attention.output.dense"), ("ln1", "attention.output.LayerNorm"),
+                                 ("up", "intermediate.dense"), ("down", "output.dense"), ("ln2", "output.LayerNorm")):
+                for p in ("weight", "bias"):
+                    if L + f"{theirs}.{p}" in sd:
+                        mapped[f"encoder.layers.{i}.{ours}.{p}"] = sd[L + f"{theirs}.{p}"]
+        for ours, theirs in (("head.weight", "classifier.weight"), ("head.bias", "classifier.bias")):
+            if ours in own and theirs in sd:
+                mapped[ours] = sd[theirs]
+        own.update({k: v.to(own[k].dtype) for k, v in mapped.items() if k in own and own[k].shape == v.shape})
+        self.module.load_state_dict(own)
+        return self
+
+
+class _SentenceModule(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.encoder = BertEncoder(c)
+
+    def forward(self, ids, types, mask):
+        h = self.encoder(ids, types, mask)
+        m = mask[..., None].to(h.dtype)
+        pooled = (h * m).sum(1) / m.sum(1).clamp_min(1.0)  # mean pooling over real tokens
+        return F.normalize(pooled.float(), dim=-1)
+
+
+class SentenceEncoder(_Base):
+    """`embedding_generator` plugin: encode_semantic / encode_semantic_batch / encode_domain (+ optional BM25
+    for encode_sparse).  Output dim = config.hidden (384 MiniLM, 768 with EncoderConfig(hidden=768, layers=12,
+    intermediate=3072) = bge-base shape)."""
+
+    def __init__(self, config: Optional[EncoderConfig] = None, device=None, dtype=None, seed: int = 0, max_len: int = 256,
+                 batch_size: int = 64, sparse_encoder=None, domain_dim: Optional[int] = None):
+        super().__init__(config, device, dtype, seed, max_len, batch_size)
+        self.module = _seeded(lambda: _SentenceModule(self.config), seed).to(self.device, self.dtype).eval()
+        self.dim = self.config.hidden
+        self.sparse_encoder = sparse_encoder
+        self.domain_dim = domain_dim or self.dim
+
+    @torch.inference_mode()
+    def encode_to_device(self, texts: Sequence[str]) -> torch.Tensor:
+        """float32 [n, dim] tensor on the encoder's device (feeds hr_add_dense_raw_dev / search without a host hop)."""
+        out = []
+        for i in range(0, len(texts), self.batch_size):
+            ids, types, mask = self.tokenizer.batch(texts[i: i + self.batch_size], device=self.device)
+            out.append(self.module(ids, types, mask))
+        return torch.cat(out) if out else torch.zeros((0, self.dim), device=self.device)
+
+    def encode_semantic_batch(self, texts: Sequence[str]) -> List[np.ndarray]:
+        return list(self.encode_to_device(list(texts)).cpu().numpy())
+
+    def encode_semantic(self, text: str) -> np.ndarray:
+        return self.encode_semantic_batch([text])[0]
+
+    def encode_domain(self, text: str, domain: Optional[str] = None) -> np.ndarray:
+        v = self.encode_semantic(f"{domain}: {text}" if domain else text)
+        if self.domain_dim == self.dim:
+            return v
+        reps = -(-self.domain_dim // self.dim)
+        return np.tile(v, reps)[: self.domain_dim].astype(np.float32)
+
+    def encode_sparse(self, text: str):
+        if self.sparse_encoder is None:
+            raise RuntimeError("no sparse encoder configured (pass sparse_encoder=BM25SparseEncoder(...))")
+        return self.sparse_encoder.encode_document(text)
+
+    def encode_sparse_query(self, text: str):
+        if self.sparse_encoder is None:
+            raise RuntimeError("no sparse encoder configured")
+        return self.sparse_encoder.encode_query(text)
+
+
+class _CrossModule(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.encoder = BertEncoder(c)
+        self.head = nn.Linear(c.hidden, 1)
+
+    def forward(self, ids, types, mask):
+        return self.head(self.encoder(ids, types, mask)[:, 0]).squeeze(-1).float()
+
+
+class CrossEncoderModel(_Base):
+    """`CrossEncoderReranker.model`: predict([(query, document), ...]) -> float32 array of relevance logits."""
+
+    def __init__(self, config: Optional[EncoderConfig] = None, device=None, dtype=None, seed: int = 1, max_len: int = 512,
+                 batch_size: int = 64):
+        super().__init__(config, device, dtype, seed, max_len, batch_size)
+        self.module = _seeded(lambda: _CrossModule(self.config), seed).to(self.device, self.dtype).eval()
+
+    @torch.inference_mode()
+    def predict_to_device(self, pairs: Sequence[Tuple[str, str]]) -> torch.Tensor:
+        out = []
+        for i in range(0, len(pairs), self.batch_size):
+            chunk = pairs[i: i + self.batch_size]
+            ids, types, mask = self.tokenizer.batch([q for q, _ in chunk], [d for _, d in chunk], device=self.device)
+            out.append(self.module(ids, types, mask))
+        return torch.cat(out) if out else torch.zeros(0, device=self.device)
+
+    def predict(self, pairs: Sequence[Tuple[str, str]]) -> np.ndarray:
+        return self.predict_to_device(list(pairs)).cpu().numpy()
+
+    def flops_per_pair(self, seq_len: int) -> float:
+        c = self.config
+        per_layer = 2 * seq_len * (4 * c.hidden * c.hidden + 2 * c.hidden * c.intermediate) + 4 * seq_len * seq_len * c.hidden
+        return float(c.layers * per_layer)

@@ -1,0 +1,91 @@
+"""Encoder / cross-encoder plugins (PyTorch): structural checks on CPU with a tiny config, and on the GPU the full
+reference-shaped flow: encoder -> index_chunks -> retrieve -> cross-encoder rerank."""
+import asyncio
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+from advanced_rag.encoders import CrossEncoderModel, EncoderConfig, HashTokenizer, SentenceEncoder  # noqa: E402
+
+TINY = EncoderConfig(vocab_size=5000, hidden=64, layers=2, heads=4, intermediate=128, max_len=64)
+
+
+def test_tokenizer_pairs_padding_and_truncation():
+    tok = HashTokenizer(5000, 16)
+    ids, types = tok.encode("Hello, world!", "second text here")
+    assert ids[0] == 101 and ids.count(102) == 2 and len(ids) == len(types) and types[-1] == 1 and types[0] == 0
+    ids, _ = tok.encode("word " * 100)
+    assert len(ids) == 16
+    ids, types, mask = tok.batch(["a b c", "d"], device="cpu")
+    assert ids.shape == types.shape == mask.shape and ids.shape[1] % 8 == 0 and mask[1].sum() == 3
+
+
+def test_sentence_encoder_cpu_shapes_determinism_and_batching():
+    enc = SentenceEncoder(TINY, device="cpu", seed=7)
+    texts = ["alpha beta gamma", "delta", "alpha beta gamma", "a much longer sentence with many more tokens in it"]
+    vs = enc.encode_semantic_batch(texts)
+    assert len(vs) == 4 and vs[0].shape == (64,) and vs[0].dtype == np.float32
+    assert np.allclose(np.linalg.norm(np.stack(vs), axis=1), 1.0, atol=1e-5)
+    assert np.allclose(vs[0], vs[2], atol=1e-6)                       # padding does not leak into the result
+    assert np.allclose(enc.encode_semantic(texts[3]), vs[3], atol=1e-5)   # batch == single
+    again = SentenceEncoder(TINY, device="cpu", seed=7).encode_semantic_batch(texts)
+    assert all(np.array_equal(a, b) for a, b in zip(again, vs))        # same seed, same weights, same call -> same bits
+    assert not np.allclose(SentenceEncoder(TINY, device="cpu", seed=8).encode_semantic(texts[1]), vs[1])
+    assert enc.encode_domain("x", "law").shape == (64,)
+    assert SentenceEncoder(TINY, device="cpu", domain_dim=100).encode_domain("x").shape == (100,)
+
+
+def test_cross_encoder_cpu_predict_and_local_weights(tmp_path):
+    ce = CrossEncoderModel(TINY, device="cpu", seed=3)
+    pairs = [("what is rag", "retrieval augmented generation"), ("what is rag", "a piece of cloth"), ("q", "d")]
+    s = ce.predict(pairs)
+    assert s.shape == (3,) and s.dtype == np.float32 and np.isfinite(s).all()
+    assert np.allclose(ce.predict(pairs[:1]), s[:1], atol=1e-5)
+    assert ce.flops_per_pair(64) > 0
+    # round-trip through a LOCAL safetensors file with HuggingFace names
+    from safetensors.torch import save_file
+    sd = ce.module.state_dict()
+    hf = {"bert.embeddings.word_embeddings.weight": sd["encoder.word.weight"] * 0 + 0.01,
+          "classifier.weight": sd["head.weight"] * 0 + 0.5, "classifier.bias": sd["head.bias"] * 0}
+    path = str(tmp_path / "m.safetensors")
+    save_file({k: v.contiguous() for k, v in hf.items()}, path)
+    ce.load_local(path)
+    assert torch.allclose(ce.module.state_dict()["head.weight"], torch.full_like(sd["head.weight"], 0.5))
+
+
+@pytest.mark.gpu
+def test_encoders_drive_the_pipeline_on_gpu(gpu):
+    from advanced_rag import AdvancedRAGPipeline, BM25SparseEncoder, CrossEncoderReranker, PipelineConfig
+    from advanced_rag.constants import RetrievalConstants
+    from advanced_rag.embedding_cache import initialize_caches
+
+    initialize_caches()
+    docs = [{"id": f"doc{i}", "text": f"Passage {i} about subject{i % 5}. It mentions item{i % 3} several times. item{i % 3} again."}
+            for i in range(40)]
+    bm25 = BM25SparseEncoder(sparse_dim=4096).fit(d["text"] for d in docs)
+    enc = SentenceEncoder(device="cuda:0", sparse_encoder=bm25, domain_dim=96, max_len=64)   # MiniLM-L6 shape, fp16
+    assert enc.dim == 384 and next(enc.module.parameters()).dtype == torch.float16
+    dev = enc.encode_to_device(["one", "two words"])
+    assert dev.is_cuda and dev.shape == (2, 384)
+    p = AdvancedRAGPipeline(config=PipelineConfig(enable_audit_logging=False, top_k=10, rerank_top_k=3),
+                            semantic_dim=384, sparse_dim=4096, domain_dim=96)
+    p.index_manager.embedding_generator = enc
+    ce = CrossEncoderModel(device="cuda:0", max_len=96)
+    p.retriever.reranker = CrossEncoderReranker(model=ce)
+    old = RetrievalConstants.TIMEOUT_SECONDS
+    RetrievalConstants.TIMEOUT_SECONDS = 60.0
+    try:
+        rep = asyncio.run(p.ingest_documents(docs))
+        assert rep["indexing_summary"]["indexed_semantic"] == rep["chunks_created"] and not rep["indexing_summary"]["errors"]
+        query = "subject2 item1"
+        raw = asyncio.run(p.retriever.retrieve(query, profile_hint="default"))
+        assert len(raw) == 10
+        want = ce.predict([(query, r["content"]) for r in raw])
+        results, _ = asyncio.run(p.retrieve(query, context={"retrieval_profile": "default"}))
+        order = np.argsort(-want, kind="stable")[:3]
+        assert [r.chunk_id for r in results] == [raw[i]["id"] for i in order]
+        assert np.allclose([r.score for r in results], want[order], atol=2e-3)
+    finally:
+        RetrievalConstants.TIMEOUT_SECONDS = old
+        asyncio.run(p.close())
