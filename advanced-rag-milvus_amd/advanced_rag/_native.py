@@ -49,6 +49,8 @@ _SIGNATURES = {
     "hr_add_dense_raw_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p]),
     "hr_add_sparse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64]),
     "hr_finalize": (_c.c_int, [_c.c_void_p]),
+    "hr_save": (_c.c_int, [_c.c_void_p, _c.c_char_p]),
+    "hr_load": (_c.c_int, [_c.c_char_p, _c.c_int, _c.POINTER(_c.c_void_p)]),
     "hr_num_rows": (_c.c_int64, [_c.c_void_p]),
     "hr_num_sparse_rows": (_c.c_int64, [_c.c_void_p]),
     "hr_device_bytes": (_c.c_int64, [_c.c_void_p]),
@@ -126,9 +128,13 @@ class ShardHandle:
     """One GPU's shard: dense tiles + sparse postings, owned by libhbmrag."""
 
     def __init__(self, dim: int, dtype: int = HR_F16, metric: int = HR_METRIC_COSINE, sparse_dim: int = 0,
-                 device: int = 0):
+                 device: int = 0, _adopt: Optional[int] = None):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
+        if _adopt is not None:  # handle created by hr_load
+            self._h = ctypes.c_void_p(_adopt)
+            self.dim, self.dtype, self.metric, self.sparse_dim, self.device = dim, dtype, metric, sparse_dim, device
+            return
         self.dim, self.dtype, self.metric, self.sparse_dim, self.device = dim, dtype, metric, sparse_dim, device
         rc = self._lib.hr_create(device, dim, dtype, metric, sparse_dim, ctypes.byref(self._h))
         if rc != 0:
@@ -159,6 +165,25 @@ class ShardHandle:
             self.close()
         except Exception:
             pass
+
+    # -- snapshot
+    def save(self, path: str):
+        self._check(self._lib.hr_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path: str, dim: int, dtype: int = HR_F16, metric: int = HR_METRIC_COSINE, sparse_dim: int = 0,
+             device: int = 0) -> "ShardHandle":
+        """Load a snapshot; dim/dtype/metric/sparse_dim describe what the caller expects (checked against the file
+        through the searches' own argument checks)."""
+        lib = load_library()
+        h = ctypes.c_void_p()
+        rc = lib.hr_load(os.fsencode(path), device, ctypes.byref(h))
+        if rc != 0:
+            msg = (lib.hr_last_error(None) or b"").decode()
+            if rc == 1:
+                raise ValueError(msg)
+            raise HbmRagError(rc, msg)
+        return cls(dim, dtype, metric, sparse_dim, device, _adopt=h.value)
 
     # -- ingest
     def set_row_offset(self, first_row: int):

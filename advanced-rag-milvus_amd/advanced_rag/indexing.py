@@ -303,6 +303,45 @@ class MilvusIndexManager:
         for coll in {id(c.handle): c for c in self.collections.values()}.values():
             coll.flush()
 
+    # ------------------------------------------------------------------ snapshot
+    def save_snapshot(self, directory: str) -> None:
+        """Write the shard(s) and the host payload columns to `directory` (resume without re-embedding)."""
+        os.makedirs(directory, exist_ok=True)
+        self.finalize()
+        self._main.save(os.path.join(directory, "main.hbmrag"))
+        if self._domain is not None:
+            self._domain.save(os.path.join(directory, "domain.hbmrag"))
+        cols = {k: np.asarray(v, dtype=str if k in ("id", "doc_id", "content", "timestamp", "metadata_json") else None)
+                for k, v in self._cols.items()}
+        deleted = self._deleted if self._deleted is not None else np.zeros(0, dtype=bool)
+        np.savez(os.path.join(directory, "payload.npz"), synthetic_rows=np.int64(self._synthetic_rows), deleted=deleted,
+                 **{f"col_{k}": v for k, v in cols.items()})
+
+    def load_snapshot(self, directory: str) -> None:
+        """Replace this manager's (empty) collections with the ones saved by `save_snapshot`."""
+        nat = self._native
+        store = nat.HR_F16 if self.dtype in ("float16", "fp16", "f16") else nat.HR_F32
+        sparse_on = "sparse_index" in self.collections
+        main = nat.ShardHandle.load(os.path.join(directory, "main.hbmrag"), self.semantic_dim, store,
+                                    nat.HR_METRIC_COSINE, self.sparse_dim if sparse_on else 0, self.device)
+        if self._main is not None:
+            self._main.close()
+        self._main = main
+        for name in ("semantic_index", "sparse_index"):
+            if name in self.collections:
+                self.collections[name].handle = main
+        dom_path = os.path.join(directory, "domain.hbmrag")
+        if self._domain is not None and os.path.exists(dom_path):
+            self._domain.close()
+            self._domain = nat.ShardHandle.load(dom_path, self.domain_dim, store, nat.HR_METRIC_COSINE, 0, self.device)
+            self.collections["domain_index"].handle = self._domain
+        with np.load(os.path.join(directory, "payload.npz"), allow_pickle=False) as z:
+            self._synthetic_rows = int(z["synthetic_rows"])
+            self._deleted = z["deleted"].copy() if z["deleted"].size else None
+            for k in self._cols:
+                self._cols[k] = z[f"col_{k}"].tolist()
+        self._np_cols = None
+
     # ------------------------------------------------------------------ search
     @staticmethod
     def _as_sparse_payload(emb):

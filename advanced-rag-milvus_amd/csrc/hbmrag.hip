@@ -839,6 +839,125 @@ int hr_finalize(hr_index* h) {
     return HR_OK;
 }
 
+namespace {
+struct SnapHeader {
+    char magic[8];
+    int32_t version, dtype, metric, KT;
+    int64_t dim, sparse_dim, n_rows, cap_rows, n_sparse, nnz, row_offset;
+    float max_row_norm, max_sparse_abs;
+};
+const char kSnapMagic[8] = {'H', 'B', 'M', 'R', 'A', 'G', '0', '1'};
+
+struct File {
+    FILE* f = nullptr;
+    ~File() { if (f) fclose(f); }
+};
+
+// device <-> file in 64 MiB pieces through a host bounce buffer
+int stream_out(hr_index* h, FILE* f, const void* dptr, size_t bytes) {
+    std::vector<char> buf(std::min<size_t>(bytes, 64u << 20));
+    for (size_t off = 0; off < bytes; off += buf.size()) {
+        const size_t n = std::min(buf.size(), bytes - off);
+        HIP_TRY(h, hipMemcpy(buf.data(), (const char*)dptr + off, n, hipMemcpyDeviceToHost));
+        if (fwrite(buf.data(), 1, n, f) != n) return fail(h, HR_EINVAL, "snapshot write failed");
+    }
+    return HR_OK;
+}
+int stream_in(hr_index* h, FILE* f, void* dptr, size_t bytes) {
+    std::vector<char> buf(std::min<size_t>(bytes, 64u << 20));
+    for (size_t off = 0; off < bytes; off += buf.size()) {
+        const size_t n = std::min(buf.size(), bytes - off);
+        if (fread(buf.data(), 1, n, f) != n) return fail(h, HR_EINVAL, "snapshot truncated");
+        HIP_TRY(h, hipMemcpy((char*)dptr + off, buf.data(), n, hipMemcpyHostToDevice));
+    }
+    return HR_OK;
+}
+}  // namespace
+
+int hr_save(hr_index* h, const char* path) {
+    if (!h || !path) return fail(h, HR_EINVAL, "null argument");
+    if (!h->finalized) return fail(h, HR_ESTATE, "hr_save before hr_finalize");
+    std::unique_lock<std::shared_mutex> lk(h->rw);
+    DeviceGuard dg(h->device);
+    HIP_TRY(h, hipDeviceSynchronize());
+    File file;
+    file.f = fopen(path, "wb");
+    if (!file.f) return fail(h, HR_EINVAL, "cannot open %s for writing", path);
+    SnapHeader hd{};
+    std::memcpy(hd.magic, kSnapMagic, 8);
+    hd.version = 1; hd.dtype = h->dtype; hd.metric = h->metric; hd.KT = h->KT;
+    hd.dim = h->dim; hd.sparse_dim = h->sparse_dim; hd.n_rows = h->n_rows;
+    hd.cap_rows = h->dim ? round_up(std::max<int64_t>(h->n_rows, 1), kSuperRows) : 0;
+    hd.n_sparse = h->n_sparse; hd.nnz = (int64_t)h->h_idx.size(); hd.row_offset = h->row_offset;
+    hd.max_row_norm = h->max_row_norm; hd.max_sparse_abs = h->max_sparse_abs;
+    if (fwrite(&hd, sizeof hd, 1, file.f) != 1) return fail(h, HR_EINVAL, "snapshot write failed");
+    if (h->dim > 0 && h->n_rows > 0) {
+        HR_TRY(stream_out(h, file.f, h->tiles.p, tile_bytes_for_rows(h, hd.cap_rows)));
+        HR_TRY(stream_out(h, file.f, h->scale.p, (size_t)hd.cap_rows * 4));
+        HR_TRY(stream_out(h, file.f, h->norm2.p, (size_t)hd.cap_rows * 8));
+    }
+    if (h->n_sparse > 0) {
+        const bool ok = fwrite(h->h_indptr.data(), 8, (size_t)h->n_sparse + 1, file.f) == (size_t)h->n_sparse + 1 &&
+                        fwrite(h->h_idx.data(), 4, (size_t)hd.nnz, file.f) == (size_t)hd.nnz &&
+                        fwrite(h->h_val.data(), 4, (size_t)hd.nnz, file.f) == (size_t)hd.nnz;
+        if (!ok) return fail(h, HR_EINVAL, "snapshot write failed");
+    }
+    return HR_OK;
+}
+
+int hr_load(const char* path, int device, hr_index** out) {
+    if (!path || !out) return fail(nullptr, HR_EINVAL, "null argument");
+    *out = nullptr;
+    File file;
+    file.f = fopen(path, "rb");
+    if (!file.f) return fail(nullptr, HR_EINVAL, "cannot open %s", path);
+    SnapHeader hd{};
+    if (fread(&hd, sizeof hd, 1, file.f) != 1 || std::memcmp(hd.magic, kSnapMagic, 8) != 0 || hd.version != 1)
+        return fail(nullptr, HR_EINVAL, "%s is not a libhbmrag snapshot (version 1)", path);
+    if (hd.n_rows < 0 || hd.n_sparse < 0 || hd.nnz < 0 || hd.cap_rows < hd.n_rows)
+        return fail(nullptr, HR_EINVAL, "corrupt snapshot header");
+    hr_index* h = nullptr;
+    HR_TRY(hr_create(device, hd.dim, hd.dtype, hd.metric, hd.sparse_dim, &h));
+    struct Guard { hr_index* h; bool keep = false; ~Guard() { if (!keep) hr_destroy(h); } } guard{h};
+    if (h->KT != hd.KT) return fail(nullptr, HR_EINVAL, "snapshot tile layout (KT=%d) differs from this build (KT=%d)", hd.KT, h->KT);
+    h->row_offset = hd.row_offset;
+    DeviceGuard dg(device);
+    if (hd.dim > 0 && hd.n_rows > 0) {
+        HR_TRY(hr_reserve(h, hd.cap_rows));
+        int rc = stream_in(h, file.f, h->tiles.p, tile_bytes_for_rows(h, hd.cap_rows));
+        if (rc == HR_OK) rc = stream_in(h, file.f, h->scale.p, (size_t)hd.cap_rows * 4);
+        if (rc == HR_OK) rc = stream_in(h, file.f, h->norm2.p, (size_t)hd.cap_rows * 8);
+        if (rc != HR_OK) return fail(nullptr, rc, "%s", hr_last_error(h));
+        h->n_rows = h->n_normed = hd.n_rows;
+        h->max_row_norm = hd.max_row_norm;
+        unsigned int bits;
+        std::memcpy(&bits, &hd.max_row_norm, 4);
+        if (hipMemcpy(h->max_norm.p, &bits, 4, hipMemcpyHostToDevice) != hipSuccess)
+            return fail(nullptr, HR_EHIP, "snapshot upload failed");
+    }
+    if (hd.n_sparse > 0) {
+        try {
+            h->h_indptr.resize((size_t)hd.n_sparse + 1);
+            h->h_idx.resize((size_t)hd.nnz);
+            h->h_val.resize((size_t)hd.nnz);
+        } catch (const std::bad_alloc&) {
+            return fail(nullptr, HR_ENOMEM, "out of host memory loading snapshot");
+        }
+        const bool ok = fread(h->h_indptr.data(), 8, (size_t)hd.n_sparse + 1, file.f) == (size_t)hd.n_sparse + 1 &&
+                        fread(h->h_idx.data(), 4, (size_t)hd.nnz, file.f) == (size_t)hd.nnz &&
+                        fread(h->h_val.data(), 4, (size_t)hd.nnz, file.f) == (size_t)hd.nnz;
+        if (!ok || h->h_indptr.front() != 0 || h->h_indptr.back() != hd.nnz)
+            return fail(nullptr, HR_EINVAL, "snapshot truncated or corrupt (sparse section)");
+        h->n_sparse = hd.n_sparse;
+        h->max_sparse_abs = hd.max_sparse_abs;
+    }
+    int rc = hr_finalize(h);
+    if (rc != HR_OK) return fail(nullptr, rc, "%s", hr_last_error(h));
+    guard.keep = true;
+    *out = h;
+    return HR_OK;
+}
+
 int64_t hr_num_rows(const hr_index* h) { return h ? h->n_rows : 0; }
 int64_t hr_num_sparse_rows(const hr_index* h) { return h ? h->n_sparse : 0; }
 int64_t hr_device_bytes(const hr_index* h) {

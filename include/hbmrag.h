@@ -111,6 +111,13 @@ HR_API int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indi
  * search workspaces.  May be called again after further adds. */
 HR_API int hr_finalize(hr_index* h);
 
+/* Shard snapshot (checkpoint / resume; the reference relies on Milvus'
+ * persistence, indexing.py:185-188, :430-431).  One file: header, dense tiles +
+ * norms exactly as they sit in HBM, and the sparse CSR; the range-major postings
+ * are rebuilt on load.  hr_load creates a finalized handle on `device`. */
+HR_API int hr_save(hr_index* h, const char* path);
+HR_API int hr_load(const char* path, int device, hr_index** out);
+
 HR_API int64_t hr_num_rows(const hr_index* h);        /* dense rows (Collection.num_entities, indexing.py:687) */
 HR_API int64_t hr_num_sparse_rows(const hr_index* h);
 HR_API int64_t hr_device_bytes(const hr_index* h);    /* HBM held by the shard */

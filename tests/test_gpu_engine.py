@@ -219,3 +219,59 @@ def test_pipelined_engine_matches_sequential(gpu):
         for k in w:
             assert torch.equal(w[k], g[k]), k
     h.close()
+
+
+def test_snapshot_roundtrip(gpu, tmp_path):
+    """hr_save / hr_load: a reloaded shard answers exactly like the original (dense, sparse, masks, offsets)."""
+    n, d, V, nnz, B = 5000, 200, 700, 9, 6
+    X, ptr, idx, val, Q, SQ = corpus(n, d, V, nnz, B, seed=77)
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    h.set_row_offset(1000)
+    h.add_dense(X)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    path = str(tmp_path / "shard.hbmrag")
+    h.save(path)
+    g = nat.ShardHandle.load(path, d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    assert (g.num_rows, g.num_sparse_rows) == (n, n)
+    mask = np.packbits(np.random.default_rng(1).random(n) < 0.5, bitorder="little")
+    for m in (None, mask):
+        a, b = h.search_dense(Q, 40, m), g.search_dense(Q, 40, m)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+        a, b = h.search_sparse(SQ, 40, 0.2, m), g.search_sparse(SQ, 40, 0.2, m)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    assert a[0].min() >= -1 and a[0][a[0] >= 0].min() >= 1000          # row offset survived
+    g.add_dense(X[:10])                                                  # a loaded shard keeps accepting rows
+    g.add_sparse(ptr[:11], idx[:ptr[10]], val[:ptr[10]])
+    g.finalize()
+    assert g.num_rows == n + 10
+    with pytest.raises(ValueError):
+        bad = tmp_path / "bad.hbmrag"
+        bad.write_bytes(b"not a snapshot")
+        nat.ShardHandle.load(str(bad), d)
+    h.close()
+    g.close()
+
+
+def test_index_manager_snapshot(gpu, tmp_path):
+    import asyncio
+    from advanced_rag import MilvusIndexManager
+    rng = np.random.default_rng(5)
+    m = MilvusIndexManager(semantic_dim=64, sparse_dim=500, domain_dim=32)
+    X = rng.standard_normal((300, 64)).astype(np.float32)
+    sp = (np.arange(301, dtype=np.int64) * 4, np.sort(rng.integers(0, 125, (300, 4)) + np.arange(4) * 125, axis=1).astype(np.int32).reshape(-1),
+          np.abs(rng.standard_normal(1200)).astype(np.float32))
+    m.add_rows(X, sp, ids=[f"c{i}" for i in range(300)], contents=[f"text {i}" for i in range(300)],
+               entropy=rng.random(300).tolist())
+    m.finalize()
+    asyncio.run(m.delete_by_filter("semantic_index", 'chunk_id == "c7"'))
+    q = X[7] + 0.01
+    before = asyncio.run(m.search(q, "semantic_index", 5, filters="entropy >= 0.3"))
+    m.save_snapshot(str(tmp_path / "snap"))
+    m2 = MilvusIndexManager(semantic_dim=64, sparse_dim=500, domain_dim=32)
+    m2.load_snapshot(str(tmp_path / "snap"))
+    after = asyncio.run(m2.search(q, "semantic_index", 5, filters="entropy >= 0.3"))
+    assert [(h["id"], h["score"], h["content"]) for h in before] == [(h["id"], h["score"], h["content"]) for h in after]
+    assert all(h["id"] != "c7" for h in after)
+    asyncio.run(m.close())
+    asyncio.run(m2.close())
