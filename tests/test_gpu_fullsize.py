@@ -1,0 +1,132 @@
+"""BASELINE config 4 at FULL size (10M x 768 fp16) through size-independent properties — the CPU oracle needs
+~10 s per query at this size, so full lists are not recomputed; instead:
+  * self-query: a stored row used as query comes back first with cosine 1.0 (and its duplicate right after, by id);
+  * ordering: scores non-increasing, equal scores in ascending id order, no id twice, flags all proven exact;
+  * invariance: the same query gives the same list alone (B=1), inside a batch of 64, and at another batch position;
+  * spot oracle: every returned (id, score) is re-scored by the CPU oracle from the regenerated row, bit for bit,
+    and no sampled non-returned row beats the k-th score;
+  * sharding: two half-corpus shards + the HIP merge kernel reproduce the whole-corpus lists exactly.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from advanced_rag import _native as nat
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+N, D, K, BLK = 10_000_000, 768, 40, 500_000
+
+
+def _block(b):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9000 + b)
+    return torch.randn((BLK, D), device="cuda", generator=g, dtype=torch.float32).to(torch.float16)
+
+
+def _rows(ids):
+    """Regenerate the given rows on the host (block-wise, deterministic)."""
+    out = np.empty((len(ids), D), dtype=np.float16)
+    ids = np.asarray(ids)
+    for b in np.unique(ids // BLK):
+        blk = _block(int(b))
+        sel = np.nonzero(ids // BLK == b)[0]
+        out[sel] = blk[torch.from_numpy(ids[sel] % BLK).cuda()].cpu().numpy()
+    return out
+
+
+@pytest.fixture(scope="module")
+def shards(gpu):
+    whole = nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE)
+    halves = [nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE) for _ in range(2)]
+    whole.reserve(N)
+    for i, h in enumerate(halves):
+        h.reserve(N // 2)
+        h.set_row_offset(i * (N // 2))
+    for b in range(N // BLK):
+        x = _block(b)
+        if b == 3:
+            x[17] = _block(0)[5]          # row 3*BLK+17 duplicates row 5: an exact tie far apart
+        torch.cuda.synchronize()
+        whole.add_dense_dev(x.data_ptr(), BLK)
+        halves[b * BLK // (N // 2)].add_dense_dev(x.data_ptr(), BLK)
+    for h in [whole] + halves:
+        h.finalize()
+    yield whole, halves
+    for h in [whole] + halves:
+        h.close()
+
+
+def test_fullsize_dense_properties(shards):
+    whole, halves = shards
+    assert whole.num_rows == N
+    rng = np.random.default_rng(1)
+    B = 64
+    Q = rng.standard_normal((B, D)).astype(np.float32)
+    probe = [5, 123_456, 9_999_999]
+    Q[:3] = _rows(probe).astype(np.float32)
+    ids, sc = whole.search_dense(Q, K)
+
+    # self-query + duplicate tie
+    assert ids[0, 0] == 5 and ids[0, 1] == 3 * BLK + 17 and sc[0, 0] == sc[0, 1] == 1.0
+    assert ids[1, 0] == probe[1] and ids[2, 0] == probe[2] and sc[1, 0] == 1.0
+    # ordering / uniqueness
+    assert (ids >= 0).all()
+    assert (np.diff(sc, axis=1) <= 0).all()
+    ties = np.diff(sc, axis=1) == 0
+    assert (np.diff(ids, axis=1)[ties] > 0).all()
+    assert all(len(set(r)) == K for r in ids.tolist())
+    # invariance: alone, and at another position inside another batch
+    for j in (0, 7, 63):
+        i1, s1 = whole.search_dense(Q[j:j + 1], K)
+        assert np.array_equal(i1[0], ids[j]) and np.array_equal(s1[0].view(np.uint32), sc[j].view(np.uint32))
+    perm = rng.permutation(B)
+    ip, sp_ = whole.search_dense(Q[perm], K)
+    assert np.array_equal(ip, ids[perm]) and np.array_equal(sp_.view(np.uint32), sc[perm].view(np.uint32))
+    # spot oracle: returned rows re-scored from regenerated data, bit for bit; sampled outsiders do not beat the k-th
+    for j in (3, 40):
+        rows = _rows(ids[j])
+        want = oracle.dense_scores(rows, Q[j], oracle.COSINE)
+        assert np.array_equal(want.view(np.uint32), sc[j].view(np.uint32))
+        outsiders = rng.integers(0, N, 20_000)
+        outsiders = outsiders[~np.isin(outsiders, ids[j])]
+        assert oracle.dense_scores(_rows(outsiders), Q[j], oracle.COSINE).max() <= sc[j, -1]
+    # device form: flags say every list is provably exact
+    dq = torch.from_numpy(Q).cuda()
+    di = torch.empty((B, K), dtype=torch.int64, device="cuda")
+    ds = torch.empty((B, K), dtype=torch.float32, device="cuda")
+    fl = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    whole.search_dense_dev(dq.data_ptr(), B, K, di.data_ptr(), ds.data_ptr(), fl.data_ptr(), 0,
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(fl.min()) == 1 and np.array_equal(di.cpu().numpy(), ids)
+
+    # sharding: two halves + merge == whole
+    G = 2
+    gs = torch.empty((G, B, K), dtype=torch.float32, device="cuda")
+    gi = torch.empty((G, B, K), dtype=torch.int64, device="cuda")
+    for r, h in enumerate(halves):
+        h.search_dense_dev(dq.data_ptr(), B, K, gi[r].data_ptr(), gs[r].data_ptr(), 0, 0,
+                           torch.cuda.current_stream().cuda_stream)
+    mi = torch.empty((B, K), dtype=torch.int64, device="cuda")
+    ms = torch.empty((B, K), dtype=torch.float32, device="cuda")
+    nat.merge_topk_dev(gs.data_ptr(), gi.data_ptr(), G, B, K, K, mi.data_ptr(), ms.data_ptr(),
+                       torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(mi.cpu().numpy(), ids) and np.array_equal(ms.cpu().numpy().view(np.uint32), sc.view(np.uint32))
+
+
+def test_fullsize_rowmask_monotone(shards):
+    """Restricting the corpus can only remove results: masked lists are the unmasked ranking filtered."""
+    whole, _ = shards
+    rng = np.random.default_rng(2)
+    Q = rng.standard_normal((4, D)).astype(np.float32)
+    ids, sc = whole.search_dense(Q, 100)
+    allow = np.ones(N, dtype=bool)
+    allow[ids[:, ::2].ravel()] = False              # knock out every other hit
+    mids, msc = whole.search_dense(Q, 40, np.packbits(allow, bitorder="little"))
+    for j in range(4):
+        kept = [i for i in ids[j].tolist() if allow[i]]
+        assert mids[j, :len(kept)].tolist()[:40] == kept[:40]
+        assert not (~allow[mids[j]]).any()
