@@ -112,7 +112,7 @@ struct hr_index {
     std::vector<float> h_val;
     int64_t n_sparse = 0, n_sparse_built = -1;
     float max_sparse_abs = 0.f;  // max |doc weight|: bounds the scan's fixed-point range
-    DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post_doc, post_val;
+    DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post;  // post: packed (fp16 weight | u16 doc)
     int64_t n_ranges = 0;
 
     bool finalized = false;
@@ -448,7 +448,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         Span sp(h, s, PH_SSCAN);
         hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(1024), 0, s,
                            h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(),
-                           h->post_doc.as<uint16_t>(), h->post_val.as<float>(), d_qptr + q0, d_qidx, d_qval,
+                           h->post.as<uint32_t>(), d_qptr + q0, d_qidx, d_qval,
                            ws->qscale.as<float>() + q0, d_mask, h->n_sparse, n_groups, GR,
                            ws->gmax.as<float>() + (int64_t)q0 * n_groups);
         HIP_TRY(h, hipGetLastError());
@@ -472,7 +472,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         // kernel) + fp32 rounding of w*scale, of the product and of the int->float
         // conversion (relative, 2^-22 with margin).
         (void)max_q_nnz;
-        const float eps_rel = (float)std::ldexp(1.0, -22);
+        const float eps_rel = (float)(std::ldexp(1.0, -11) * 1.01 + std::ldexp(1.0, -22));  // fp16 posting weights
         hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, s, ws->cscore.as<float>(),
                            ws->crow.as<int32_t>(), C * GR, k, h->row_offset, ws->acut.as<float>(), 0.0f, 0.0f,
                            ws->qeps.as<float>(), eps_rel, 0, (const double*)nullptr, d_ids, d_scores, d_flags);
@@ -600,8 +600,7 @@ int build_sparse(hr_index* h) {
     const size_t off_bytes = (size_t)h->n_ranges * V1 * 4;
     HIP_TRY(h, h->rt_off.ensure(off_bytes));
     HIP_TRY(h, h->range_base.ensure((size_t)(h->n_ranges + 1) * 8));
-    HIP_TRY(h, h->post_doc.ensure((size_t)std::max<int64_t>(nnz, 1) * 2));
-    HIP_TRY(h, h->post_val.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    HIP_TRY(h, h->post.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
     HIP_TRY(h, hipMemsetAsync(h->rt_off.p, 0, off_bytes, s));
     const unsigned doc_blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(sparse_count_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
@@ -626,7 +625,7 @@ int build_sparse(hr_index* h) {
     HIP_TRY(h, hipMemcpyAsync(cursor.p, h->rt_off.p, off_bytes, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(sparse_fill_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
                        h->s_idx.as<int32_t>(), h->s_val.as<float>(), n, V1, cursor.as<unsigned int>(),
-                       h->range_base.as<int64_t>(), h->post_doc.as<uint16_t>(), h->post_val.as<float>());
+                       h->range_base.as<int64_t>(), h->post.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
     totals.release();
@@ -707,7 +706,7 @@ void hr_destroy(hr_index* h) {
         for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
         for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
         for (DevBuf* b : {&h->tiles, &h->scale, &h->norm2, &h->max_norm, &h->stage, &h->s_indptr, &h->s_idx, &h->s_val,
-                          &h->rt_off, &h->range_base, &h->post_doc, &h->post_val})
+                          &h->rt_off, &h->range_base, &h->post})
             b->release();
         if (h->ingest_stream) (void)hipStreamDestroy(h->ingest_stream);
     }
@@ -789,6 +788,8 @@ int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indices, co
                 return fail(h, HR_EINVAL, "sparse index %d out of range [0,%lld) in row %lld", t, (long long)h->sparse_dim, (long long)r);
             if (t <= prev) return fail(h, HR_EINVAL, "sparse indices must be strictly ascending (row %lld)", (long long)r);
             if (!std::isfinite(values[e])) return fail(h, HR_EINVAL, "non-finite sparse value in row %lld", (long long)r);
+            if (std::fabs(values[e]) > 60000.f)
+                return fail(h, HR_ELIMIT, "sparse weight %g in row %lld exceeds the fp16 posting range", (double)values[e], (long long)r);
             batch_max = std::max(batch_max, std::fabs(values[e]));
             prev = t;
         }
@@ -964,7 +965,7 @@ int64_t hr_device_bytes(const hr_index* h) {
     if (!h) return 0;
     size_t t = 0;
     for (const DevBuf* b : {&h->tiles, &h->scale, &h->norm2, &h->s_indptr, &h->s_idx, &h->s_val, &h->rt_off,
-                            &h->range_base, &h->post_doc, &h->post_val})
+                            &h->range_base, &h->post})
         t += b->cap;
     return (int64_t)t;
 }

@@ -59,13 +59,30 @@ __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int*
     }
 }
 
+// A posting is 4 bytes: fp16 weight (high half) | uint16 doc id local to the range.
+// The scan is only the candidate generator (the refine recomputes from the fp32
+// CSR), so the weight may be rounded; a positive weight never rounds to zero, so
+// "accumulator > 0  <=>  some positive product" still holds.
+__device__ inline uint32_t pack_posting(uint16_t local_doc, float w) {
+    union { _Float16 h; unsigned short u; } cv;
+    cv.h = (_Float16)w;  // round to nearest even
+    unsigned short hb = cv.u;
+    if ((hb & 0x7FFFu) == 0 && w != 0.f) hb = (unsigned short)((w < 0.f ? 0x8000u : 0u) | 1u);  // keep the sign, min subnormal
+    return ((uint32_t)hb << 16) | local_doc;
+}
+__device__ inline float posting_weight(uint32_t p) {
+    union { _Float16 h; unsigned short u; } cv;
+    cv.u = (unsigned short)(p >> 16);
+    return (float)cv.h;
+}
+
 // Scatter postings.  cursor = copy of rt_off; order inside a run follows the
 // atomics (the scan's sums are order-independent up to fp32 rounding, which
 // the refine step makes irrelevant).
 __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
                                    const float* __restrict__ val, int64_t n_docs, int64_t V1,
                                    unsigned int* __restrict__ cursor, const int64_t* __restrict__ range_base,
-                                   uint16_t* __restrict__ post_doc, float* __restrict__ post_val) {
+                                   uint32_t* __restrict__ post) {
     int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_docs) return;
     const int64_t range = d / kRangeDocs;
@@ -74,8 +91,7 @@ __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int
     const uint16_t local = (uint16_t)(d - range * kRangeDocs);
     for (int64_t e = indptr[d]; e < indptr[d + 1]; ++e) {
         unsigned int slot = atomicAdd(&cur[idx[e]], 1u);
-        post_doc[base + slot] = local;
-        post_val[base + slot] = val[e];
+        post[base + slot] = pack_posting(local, val[e]);
     }
 }
 
@@ -91,6 +107,9 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
                                                                 const float* __restrict__ q_val, float max_doc_w,
                                                                 float* __restrict__ q_scale,
                                                                 float* __restrict__ q_eps) {
+    // q_eps = absolute part of the scan's error bound: fixed-point rounding (nnz+1)/scale plus the
+    // fp16 floor of tiny doc weights (6e-8 per unit of query weight); the relative part (fp16
+    // rounding of normal weights, 2^-11) is passed to select_topk as eps_rel.
     __shared__ float part[256];
     const int qi = blockIdx.x, tid = threadIdx.x;
     const int64_t t0 = q_indptr[qi], t1 = q_indptr[qi + 1];
@@ -106,7 +125,7 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
         const float bound = part[0] * max_doc_w;
         const float scale = bound > 0.f ? 1073741824.0f / bound : 0.f;
         q_scale[qi] = scale;
-        q_eps[qi] = scale > 0.f ? (float)(t1 - t0 + 1) / scale : 0.f;
+        q_eps[qi] = scale > 0.f ? (float)(t1 - t0 + 1) / scale + part[0] * 6.0e-8f : 0.f;
     }
 }
 
@@ -117,8 +136,8 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
 // maxima leave the CU.  Work is cut into items of kItemPostings consecutive
 // postings of one run; each wave takes items in a strided loop, kItemsInFlight
 // at a time, so it keeps 8 independent coalesced loads in flight instead of one.
-// Algorithmic HBM bytes per (query, range): sum over query terms of run_len * 6
-// (uint16 doc + fp32 weight) + 2*4 per term for the run bounds + 256*4 out.
+// Algorithmic HBM bytes per (query, range): sum over query terms of run_len * 4
+// (packed uint16 doc + fp16 weight) + 2*4 per term for the run bounds + group maxima out.
 constexpr int kItemPostings = 64;
 constexpr int kItemsInFlight = 8;
 constexpr int kItemTable = 4096;  // items whose run is looked up from a table instead of searched
@@ -133,7 +152,7 @@ __device__ inline int acc_index(int d) { return d + (d >> 4); }
 
 __global__ __launch_bounds__(1024) void sparse_scan_kernel(
     const unsigned int* __restrict__ rt_off, int64_t V1, const int64_t* __restrict__ range_base,
-    const uint16_t* __restrict__ post_doc, const float* __restrict__ post_val,
+    const uint32_t* __restrict__ post,
     const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
     const float* __restrict__ q_val, const float* __restrict__ q_scale, const uint8_t* __restrict__ rowmask,
     int64_t n_docs, int64_t n_groups, int group_docs, float* __restrict__ gmax) {
@@ -151,8 +170,7 @@ __global__ __launch_bounds__(1024) void sparse_scan_kernel(
         for (int i = tid; i < (kRangeDocs + kRangeDocs / 16) / 4; i += 1024) a4[i] = make_int4(0, 0, 0, 0);
     }
     const unsigned int* offs = rt_off + range * V1;
-    const uint16_t* pd = post_doc + range_base[range];
-    const float* pv = post_val + range_base[range];
+    const uint32_t* pp = post + range_base[range];
     const int64_t t0 = q_indptr[qi], t1 = q_indptr[qi + 1];
     const float scale = q_scale[qi];
 
@@ -218,16 +236,13 @@ __global__ __launch_bounds__(1024) void sparse_scan_kernel(
                     w[u] = run_w[lo];
                 }
             }
-            uint16_t d[kItemsInFlight];
-            float v[kItemsInFlight];
+            uint32_t pk[kItemsInFlight];
 #pragma unroll
-            for (int u = 0; u < kItemsInFlight; ++u) {  // every load is issued before the first use
-                d[u] = ok[u] ? pd[e[u]] : (uint16_t)0;
-                v[u] = ok[u] ? pv[e[u]] : 0.f;
-            }
+            for (int u = 0; u < kItemsInFlight; ++u)  // every load is issued before the first use
+                pk[u] = ok[u] ? pp[e[u]] : 0u;
 #pragma unroll
             for (int u = 0; u < kItemsInFlight; ++u)
-                if (ok[u]) atomicAdd(&acc[acc_index(d[u])], fixed_contrib(w[u] * v[u]));
+                if (ok[u]) atomicAdd(&acc[acc_index((int)(pk[u] & 0xFFFFu))], fixed_contrib(w[u] * posting_weight(pk[u])));
         }
     }
     __syncthreads();
