@@ -96,3 +96,59 @@ def test_errors(gpu):
     h.close()
     with pytest.raises(ValueError):
         nat.ShardHandle(0, nat.HR_F16, nat.HR_METRIC_COSINE, 0)
+
+
+def test_ties_at_the_cut_force_escalation(gpu):
+    """Thousands of identical rows: the candidate-group cut cannot separate them, so the device form must flag the
+    lists as not proven and the host form must escalate (4x candidates, then every group) and still return the
+    oracle's answer: the lowest row ids among the tied rows."""
+    import torch
+    rng = np.random.default_rng(11)
+    d, n_dup = 96, 6000
+    proto = rng.standard_normal(d).astype(np.float16)
+    X = np.concatenate([rng.standard_normal((3000, d)).astype(np.float16), np.tile(proto, (n_dup, 1)),
+                        rng.standard_normal((2000, d)).astype(np.float16)])
+    Q = np.stack([proto.astype(np.float32), rng.standard_normal(d).astype(np.float32)])
+    for metric in (nat.HR_METRIC_COSINE, nat.HR_METRIC_IP):
+        h = nat.ShardHandle(d, nat.HR_F16, metric)
+        h.add_dense(X)
+        h.finalize()
+        ids, sc = h.search_dense(Q, 50)
+        oids, osc = oracle.dense_search(X, Q, 50, metric)
+        assert np.array_equal(ids, oids) and np.array_equal(_bits(sc), _bits(osc))
+        assert ids[0].tolist() == list(range(3000, 3050))
+        dq = torch.from_numpy(Q).cuda()
+        di = torch.empty((2, 50), dtype=torch.int64, device="cuda")
+        ds = torch.empty((2, 50), dtype=torch.float32, device="cuda")
+        fl = torch.ones((2,), dtype=torch.int32, device="cuda")
+        h.search_dense_dev(dq.data_ptr(), 2, 50, di.data_ptr(), ds.data_ptr(), fl.data_ptr(), 0,
+                           torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert fl.tolist() == [0, 1]          # the tied query is honestly reported as "not proven"; the other is
+        h.close()
+
+
+def test_concurrent_searches_from_threads(gpu):
+    """Searches are mutually thread-safe (private workspace + stream per call): the reference runs its two
+    modality searches in worker threads (indexing.py:504-506) under up to 64 in-flight requests."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = np.random.default_rng(12)
+    X = rng.standard_normal((40000, 256)).astype(np.float16)
+    h = nat.ShardHandle(256, nat.HR_F16, nat.HR_METRIC_COSINE)
+    h.add_dense(X)
+    h.finalize()
+    Qs = [rng.standard_normal((b, 256)).astype(np.float32) for b in (1, 3, 16, 5, 33, 2, 64, 7)]
+    want = [h.search_dense(q, 40) for q in Qs]
+
+    def work(i):
+        out = []
+        for _ in range(6):
+            out.append(h.search_dense(Qs[i], 40))
+        return out
+
+    with ThreadPoolExecutor(8) as pool:
+        got = list(pool.map(work, range(len(Qs))))
+    for w, outs in zip(want, got):
+        for g in outs:
+            assert np.array_equal(w[0], g[0]) and np.array_equal(_bits(w[1]), _bits(g[1]))
+    h.close()

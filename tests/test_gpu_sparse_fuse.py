@@ -143,3 +143,38 @@ def test_merge_topk_and_batched_rrf_dev(gpu):
         assert np.array_equal(fo[i, :n].cpu().numpy(), oi_[:n])
         assert np.array_equal(fs[i, :n].cpu().numpy().view(np.uint64), os2[:n].view(np.uint64))
         assert np.array_equal(fm[i, :n].cpu().numpy(), om[:n])
+
+
+def test_sparse_ties_and_few_positive_docs(gpu):
+    """(a) many identical sparse rows -> ties at the cut -> escalation, lowest ids win; (b) a query that matches
+    fewer than k docs returns exactly those, -1 padded, and is still proven exact (nothing outside can be > 0)."""
+    import torch
+    rng = np.random.default_rng(13)
+    V, n = 400, 40000
+    idx = np.tile(np.array([3, 50, 77, 200], np.int32), n)
+    val = np.tile(np.array([0.5, 1.0, 0.25, 2.0], np.float32), n)
+    ptr = np.arange(n + 1, dtype=np.int64) * 4
+    idx = idx.copy()
+    idx[4 * 123 + 1] = 51                      # one row differs
+    rare = np.array([399], np.int32)
+    idx[4 * 20000 + 3] = 399                   # exactly one doc holds term 399
+    queries = [(np.array([50, 200], np.int32), np.array([1.0, 1.0], np.float32)), (rare, np.ones(1, np.float32))]
+    h = nat.ShardHandle(0, sparse_dim=V)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    ids, sc = h.search_sparse(queries, 60, 0.0)
+    oids, osc = oracle.sparse_search(ptr, idx, val, queries, 60, 0.0)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sc), _bits(osc))
+    assert ids[1].tolist() == [20000] + [-1] * 59
+    st = torch.cuda.current_stream().cuda_stream
+    from advanced_rag.engine import pack_sparse_queries
+    p, i_, v_, mx = pack_sparse_queries(queries, 0.0)
+    dp, di_, dv_ = (torch.from_numpy(a).cuda() for a in (p, i_, v_))
+    oi = torch.empty((2, 60), dtype=torch.int64, device="cuda")
+    os_ = torch.empty((2, 60), dtype=torch.float32, device="cuda")
+    fl = torch.ones((2,), dtype=torch.int32, device="cuda")
+    h.search_sparse_dev(dp.data_ptr(), di_.data_ptr(), dv_.data_ptr(), 2, len(i_), mx, 60, oi.data_ptr(), os_.data_ptr(),
+                        fl.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    assert fl.tolist() == [0, 1]
+    h.close()
