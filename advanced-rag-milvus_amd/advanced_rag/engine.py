@@ -225,6 +225,33 @@ class HybridSearchEngine:
         b["list_ids"], b["list_scores"] = ids, scores
         return b
 
+    def resolve_inexact(self, b: dict, q_host: np.ndarray, sparse_host=None, drop_ratio: float = 0.0) -> int:
+        """The device forms report, per (modality, query), whether the list is PROVEN exact.  For the rare ones
+        that are not (ties at the candidate cut), redo those queries through the host forms — which widen the
+        candidate set until the proof holds — patch the lists and redo fusion/rerank.  `sparse_host` holds the
+        queries as given to pack_sparse_queries (before the drop).  Returns the number of lists redone; call after
+        synchronising the batch.  Single-shard only: every rank of a sharded corpus must call its own."""
+        t = self.torch
+        flags = b["flags"].cpu().numpy()
+        redone = 0
+        B = flags.shape[1]
+        for m in range(b["n_mod"]):
+            bad = np.nonzero(flags[m] == 0)[0]
+            if not len(bad):
+                continue
+            if m == 0:
+                ids, sc = self.h.search_dense(np.ascontiguousarray(q_host[bad]), b["kp"])
+            else:
+                ids, sc = self.h.search_sparse([sparse_host[i] for i in bad], b["kp"], drop_ratio)
+            sel = t.from_numpy(bad).to(self.device)
+            b["ids"][m].index_copy_(0, sel, t.from_numpy(ids).to(self.device))
+            b["scores"][m].index_copy_(0, sel, t.from_numpy(sc).to(self.device))
+            b["flags"][m].index_fill_(0, sel, 1)
+            redone += len(bad)
+        if redone:
+            self._post_lists(b, B, t.cuda.current_stream(self.device).cuda_stream)
+        return redone
+
     def upload_sparse(self, packed):
         t = self.torch
         indptr, idx, val, max_nnz = packed

@@ -275,3 +275,37 @@ def test_index_manager_snapshot(gpu, tmp_path):
     assert all(h["id"] != "c7" for h in after)
     asyncio.run(m.close())
     asyncio.run(m2.close())
+
+
+def test_engine_resolves_unproven_lists(gpu):
+    """Ties at the candidate cut: the batched path flags them, resolve_inexact() repairs lists + fusion to the oracle."""
+    rng = np.random.default_rng(31)
+    d, V = 64, 300
+    proto = rng.standard_normal(d).astype(np.float16)
+    X = np.concatenate([rng.standard_normal((2000, d)).astype(np.float16), np.tile(proto, (5000, 1)),
+                        rng.standard_normal((1000, d)).astype(np.float16)])
+    n = X.shape[0]
+    idx = np.sort(np.argpartition(rng.random((n, V)), 5, axis=1)[:, :6], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * 6)).astype(np.float32)
+    ptr = np.arange(n + 1, dtype=np.int64) * 6
+    Q = np.stack([proto.astype(np.float32)] + [rng.standard_normal(d).astype(np.float32) for _ in range(3)])
+    SQ = [(np.sort(rng.choice(V, 20, replace=False)).astype(np.int32), np.abs(rng.standard_normal(20)).astype(np.float32))
+          for _ in range(4)]
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    h.add_dense(X)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    cfg = EngineConfig(top_k=20)
+    eng = HybridSearchEngine(h, cfg)
+    out = eng.search(torch.from_numpy(Q).cuda(), eng.upload_sparse(pack_sparse_queries(SQ, 0.2)))
+    torch.cuda.synchronize()
+    assert out["flags"][0, 0].item() == 0
+    assert eng.resolve_inexact(out, Q, SQ, 0.2) >= 1
+    torch.cuda.synchronize()
+    (di, ds), (si, ss), fused, reranked = oracle_pipeline(X, ptr, idx, val, Q, SQ, cfg)
+    assert np.array_equal(out["ids"][0].cpu().numpy(), di) and np.array_equal(out["ids"][1].cpu().numpy(), si)
+    for b in range(4):
+        nf = int(out["fused_n"][b])
+        assert np.array_equal(out["fused_ids"][b, :nf].cpu().numpy(), fused[b][0])
+        assert np.array_equal(out["rr_ids"][b, :len(reranked[b][0])].cpu().numpy(), reranked[b][0])
+    h.close()
