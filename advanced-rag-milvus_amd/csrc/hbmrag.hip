@@ -61,12 +61,12 @@ struct Workspace {
     hipStream_t side = nullptr;    // side stream + events of hr_search_hybrid_dev
     hipEvent_t ev_scan = nullptr, ev_side = nullptr;
     struct Workspace* sparse_ws = nullptr;  // private buffers of the sparse chain when it runs concurrently
-    DevBuf qfrag, qn2, gmax, bmax, cand, acut, cscore, crow, flags, qscale, qeps;
+    DevBuf qfrag, qn2, gmax, bmax, cand, acut, cscore, crow, flags, qscale, qeps, pq_n, pq_idx, pq_w;
     DevBuf d_q, d_ids, d_scores, d_mask;          // host-form staging
     DevBuf d_qptr, d_qidx, d_qval;                // sparse query staging
     DevBuf f_ids, f_out_ids, f_out_scores, f_out_meth, f_n;  // hr_fuse_rrf staging
     void release() {
-        for (DevBuf* b : {&qfrag, &qn2, &gmax, &bmax, &qscale, &qeps, &cand, &acut, &cscore, &crow, &flags, &d_q, &d_ids, &d_scores,
+        for (DevBuf* b : {&qfrag, &qn2, &gmax, &bmax, &qscale, &qeps, &pq_n, &pq_idx, &pq_w, &cand, &acut, &cscore, &crow, &flags, &d_q, &d_ids, &d_scores,
                           &d_mask, &d_qptr, &d_qidx, &d_qval, &f_ids, &f_out_ids, &f_out_scores, &f_out_meth, &f_n})
             b->release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -438,9 +438,14 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     HIP_TRY(h, ws->qscale.ensure((size_t)B * sizeof(float)));
     HIP_TRY(h, ws->qeps.ensure((size_t)B * sizeof(float)));
     const int64_t V1 = h->sparse_dim + 1;
+    const int stride = (int)round_up(std::max(max_q_nnz, 1), 64);  // fixed-stride query layout for the scan
     if (phases & PHASE_SCAN) {
-        hipLaunchKernelGGL(sparse_query_prep_kernel, dim3(B), dim3(256), 0, s, d_qptr, d_qval, h->max_sparse_abs,
-                           ws->qscale.as<float>(), ws->qeps.as<float>());
+        HIP_TRY(h, ws->pq_n.ensure((size_t)B * 4));
+        HIP_TRY(h, ws->pq_idx.ensure((size_t)B * stride * 4));
+        HIP_TRY(h, ws->pq_w.ensure((size_t)B * stride * 4));
+        hipLaunchKernelGGL(sparse_query_prep_kernel, dim3(B), dim3(256), 0, s, d_qptr, d_qidx, d_qval,
+                           h->max_sparse_abs, stride, ws->qscale.as<float>(), ws->qeps.as<float>(),
+                           ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>());
         HIP_TRY(h, hipGetLastError());
     }
     for (int q0 = 0; (phases & PHASE_SCAN) && q0 < B; q0 += 32768) {  // gridDim.y limit
@@ -448,8 +453,9 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         Span sp(h, s, PH_SSCAN);
         hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(1024), 0, s,
                            h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(),
-                           h->post.as<uint32_t>(), d_qptr + q0, d_qidx, d_qval,
-                           ws->qscale.as<float>() + q0, d_mask, h->n_sparse, n_groups, GR,
+                           h->post.as<uint32_t>(), ws->pq_n.as<int32_t>() + q0,
+                           ws->pq_idx.as<int32_t>() + (int64_t)q0 * stride, ws->pq_w.as<float>() + (int64_t)q0 * stride,
+                           stride, ws->qscale.as<float>() + q0, d_mask, h->n_sparse, n_groups, GR,
                            ws->gmax.as<float>() + (int64_t)q0 * n_groups);
         HIP_TRY(h, hipGetLastError());
     }
@@ -471,7 +477,6 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         // scan error = fixed-point rounding ((nnz+1)/scale per query, from the prep
         // kernel) + fp32 rounding of w*scale, of the product and of the int->float
         // conversion (relative, 2^-22 with margin).
-        (void)max_q_nnz;
         const float eps_rel = (float)(std::ldexp(1.0, -11) * 1.01 + std::ldexp(1.0, -22));  // fp16 posting weights
         hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, s, ws->cscore.as<float>(),
                            ws->crow.as<int32_t>(), C * GR, k, h->row_offset, ws->acut.as<float>(), 0.0f, 0.0f,

@@ -103,10 +103,16 @@ __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int
 // Each contribution is rounded AWAY from zero (a positive product always counts
 // at least 1), hence |fixed/scale - exact| <= (nnz+1)/scale: that bound is
 // written to q_eps for the exactness check of select_topk.
+// It also re-lays the CSR queries out at a fixed stride (pq_idx / pq_w = weight*scale, zero padded,
+// pq_n = term count), so a scan block can fetch its query's terms without first waiting for q_indptr:
+// one dependent round trip less per block.
 __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* __restrict__ q_indptr,
+                                                                const int32_t* __restrict__ q_idx,
                                                                 const float* __restrict__ q_val, float max_doc_w,
-                                                                float* __restrict__ q_scale,
-                                                                float* __restrict__ q_eps) {
+                                                                int stride, float* __restrict__ q_scale,
+                                                                float* __restrict__ q_eps, int32_t* __restrict__ pq_n,
+                                                                int32_t* __restrict__ pq_idx,
+                                                                float* __restrict__ pq_w) {
     // q_eps = absolute part of the scan's error bound: fixed-point rounding (nnz+1)/scale plus the
     // fp16 floor of tiny doc weights (6e-8 per unit of query weight); the relative part (fp16
     // rounding of normal weights, 2^-11) is passed to select_topk as eps_rel.
@@ -121,11 +127,20 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
         if (tid < off) part[tid] += part[tid + off];
         __syncthreads();
     }
+    const float bound = part[0] * max_doc_w;
+    const float scale = bound > 0.f ? 1073741824.0f / bound : 0.f;
     if (tid == 0) {
-        const float bound = part[0] * max_doc_w;
-        const float scale = bound > 0.f ? 1073741824.0f / bound : 0.f;
         q_scale[qi] = scale;
-        q_eps[qi] = scale > 0.f ? (float)(t1 - t0 + 1) / scale + part[0] * 6.0e-8f : 0.f;
+        // a query longer than the caller's max_q_nnz would be truncated by the fixed-stride layout: make its
+        // list "never proven" so it is redone through the host form
+        q_eps[qi] = (t1 - t0 > stride) ? __builtin_inff()
+                                       : (scale > 0.f ? (float)(t1 - t0 + 1) / scale + part[0] * 6.0e-8f : 0.f);
+        pq_n[qi] = (int32_t)min((int64_t)stride, t1 - t0);
+    }
+    for (int i = tid; i < stride; i += 256) {
+        const bool in = t0 + i < t1;
+        pq_idx[(int64_t)qi * stride + i] = in ? q_idx[t0 + i] : 0;
+        pq_w[(int64_t)qi * stride + i] = in ? q_val[t0 + i] * scale : 0.f;
     }
 }
 
@@ -153,8 +168,8 @@ __device__ inline int acc_index(int d) { return d + (d >> 4); }
 __global__ __launch_bounds__(1024) void sparse_scan_kernel(
     const unsigned int* __restrict__ rt_off, int64_t V1, const int64_t* __restrict__ range_base,
     const uint32_t* __restrict__ post,
-    const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
-    const float* __restrict__ q_val, const float* __restrict__ q_scale, const uint8_t* __restrict__ rowmask,
+    const int32_t* __restrict__ pq_n, const int32_t* __restrict__ pq_idx, const float* __restrict__ pq_w,
+    int stride, const float* __restrict__ q_scale, const uint8_t* __restrict__ rowmask,
     int64_t n_docs, int64_t n_groups, int group_docs, float* __restrict__ gmax) {
     __shared__ int acc[kRangeDocs + kRangeDocs / 16];
     __shared__ uint8_t item_run[kItemTable];
@@ -171,19 +186,25 @@ __global__ __launch_bounds__(1024) void sparse_scan_kernel(
     }
     const unsigned int* offs = rt_off + range * V1;
     const uint32_t* pp = post + range_base[range];
-    const int64_t t0 = q_indptr[qi], t1 = q_indptr[qi + 1];
+    // every load below is independent of the others except run bounds <- term: two round trips, not three
+    const int n_terms = pq_n[qi];
     const float scale = q_scale[qi];
+    const int32_t* my_idx = pq_idx + (int64_t)qi * stride;
+    const float* my_w = pq_w + (int64_t)qi * stride;
 
-    for (int64_t tc = t0; tc < t1; tc += kScanTermChunk) {
-        const int nt = (int)((t1 - tc) < kScanTermChunk ? (t1 - tc) : kScanTermChunk);
+    for (int tc = 0; tc == 0 || tc < n_terms; tc += kScanTermChunk) {
+        // speculative fetch: slots past the query's length hold term 0 / weight 0 (padding written by the prep)
+        const bool slot = tid < kScanTermChunk && tc + tid < stride;
+        const int32_t t = slot ? my_idx[tc + tid] : 0;
+        const float wq = slot ? my_w[tc + tid] : 0.f;
+        const unsigned int lo = slot ? offs[t] : 0u, hi = slot ? offs[t + 1] : 0u;
+        const int nt = min(kScanTermChunk, max(n_terms - tc, 0));
         __syncthreads();
         unsigned int items = 0;
         if (tid < nt) {
-            const int32_t t = q_idx[tc + tid];
-            const unsigned int lo = offs[t], hi = offs[t + 1];
             run_lo[tid] = lo;
             run_hi[tid] = hi;
-            run_w[tid] = q_val[tc + tid] * scale;
+            run_w[tid] = wq;
             items = (hi - lo + kItemPostings - 1) / kItemPostings;
         }
         // exclusive scan of `items` over the first 256 threads (4 waves)
