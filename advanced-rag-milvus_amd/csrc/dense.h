@@ -4,6 +4,8 @@
 // Replaces the server-side HNSW/COSINE search behind Collection.search
 // (reference src/advanced_rag/indexing.py:503-525) with an exact FLAT scan.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace hbmrag {
@@ -243,6 +245,171 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
         if (NRB != 1) {
 #pragma unroll
             for (int g = 0; g < G; ++g) {
+                float v = m[g];
+                v = fmaxf(v, __shfl_xor(v, 16));
+                v = fmaxf(v, __shfl_xor(v, 32));
+                if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * gmax_stride + group] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Large-batch scan: 16*GQ = 128 queries per pass (GQ = 8 is what is instantiated: at GQ = 16 the
+// 2 x 16 x 4 accumulators push hipcc into scratch and the pass runs at half the HBM rate, i.e. no
+// better than two 128-query passes — measured 5.79 ms vs 2 x 2.76 ms at 10M x 768).  The whole query
+// tile no longer fits LDS (128 x 1024 fp16 = 256 KiB), so it is streamed through LDS in
+// k-chunks of BKT = 2 MFMA steps, double buffered and shared by the block's 8
+// waves, which therefore walk k in lockstep (one __syncthreads per chunk) while
+// each wave keeps its own 2 row blocks' accumulators (2 x GQ x 4 registers) and
+// still streams its corpus tiles straight from HBM into the register ring.
+// Per round a block reads 8 x 2 row blocks from HBM and the query tile once from
+// L2: L2 : HBM traffic = 1 : 1.  MFMA work per corpus KiB is GQ x 16 cycles per
+// SIMD (GQ = 16: 64 cycles per KiB per CU against ~100 cycles per KiB of HBM
+// supply), so the pass stays HBM-bound.
+template <typename STORE, int GQ, int NRB>
+__global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
+    const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
+    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int KT, int64_t n_rows,
+    int64_t n_super) {
+    constexpr int RS = 2, BKT = 2, PF = 4;  // query chunk = 2 k-steps (16 staging registers), corpus ring = 4 k-steps
+    constexpr int kPairs = kRowBlocksPerSuper / RS;
+    constexpr int kFrags = GQ * BKT;           // 1 KiB query fragments per k-chunk
+    constexpr int kStage = kFrags / 8;         // fragments each of the 8 waves stages per chunk
+    static_assert(kFrags % 8 == 0, "8 waves share the staging");
+    static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
+    extern __shared__ chunk_t lds_q[];         // [2][GQ][BKT][64]
+    static_assert(PF == 2 * BKT, "two query chunks per trip of the ring");
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 8 + wid));
+    const int64_t total_waves = (int64_t)gridDim.x * 8;
+    const int64_t gmax_stride = n_super * (kRowBlocksPerSuper / NRB);
+    const int quad = lane >> 4;
+    const float NEG_INF = -__builtin_inff();
+    const int n_chunks = KT / BKT;
+    const int64_t n_rounds = (n_super + total_waves - 1) / total_waves;  // the same for every wave: lockstep
+
+    // corpus prefetch cursor (as in dense_scan_kernel); past the end (and for idle waves) re-read a valid group
+    const int64_t safe_group = wave % n_super;
+    int64_t pf_group = wave;
+    int pf_pair = 0, pf_kt = 0;
+    chunk_t ring[PF][RS];
+    auto prefetch = [&](int slot) {
+        const int64_t grp = pf_group < n_super ? pf_group : safe_group;
+        const int64_t rb = grp * kRowBlocksPerSuper + pf_pair * RS;
+#pragma unroll
+        for (int s = 0; s < RS; ++s)
+            ring[slot][s] = __builtin_nontemporal_load(tiles + ((rb + s) * KT + pf_kt) * kTileChunks + lane);
+        const bool wrap_kt = (pf_kt + 1 == KT);
+        pf_kt = wrap_kt ? 0 : pf_kt + 1;
+        const bool wrap_pair = wrap_kt && (pf_pair + 1 == kPairs);
+        pf_pair = wrap_kt ? (wrap_pair ? 0 : pf_pair + 1) : pf_pair;
+        pf_group = wrap_pair ? pf_group + total_waves : pf_group;
+    };
+    // query chunk staging: wave `wid` moves fragments wid*kStage .. +kStage of a chunk (f = g*BKT + kk)
+    auto q_src = [&](int chunk, int f) {
+        const int g = f / BKT, kk = f % BKT;
+        return qfrag + ((int64_t)g * KT + chunk * BKT + kk) * kTileChunks + lane;
+    };
+    // prologue: chunk 0 into buffer 0
+#pragma unroll
+    for (int i = 0; i < kStage; ++i) {
+        const int f = wid * kStage + i;
+        lds_q[f * kTileChunks + lane] = *q_src(0, f);
+    }
+#pragma unroll
+    for (int j = 0; j < PF; ++j) prefetch(j);
+    __syncthreads();
+    int cur = 0;
+
+    for (int64_t round = 0; round < n_rounds; ++round) {
+        const int64_t group = round * total_waves + wave;
+        const bool live = group < n_super;
+        float m[GQ];
+#pragma unroll
+        for (int g = 0; g < GQ; ++g) m[g] = NEG_INF;
+        const bool tail = live && ((group + 1) * kSuperRows > n_rows || rowmask != nullptr);
+#pragma unroll 1
+        for (int pair = 0; pair < kPairs; ++pair) {
+            f32x4_t acc[RS][GQ];
+#pragma unroll
+            for (int s = 0; s < RS; ++s)
+#pragma unroll
+                for (int g = 0; g < GQ; ++g) acc[s][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            // one query chunk: stage the NEXT chunk (wrapping to chunk 0 for the next pair / round) into
+            // registers, run this chunk's MFMAs out of LDS buffer `cur`, then publish the staged chunk.
+            // SB = first ring slot of the chunk (compile-time: the ring holds two chunks).
+            auto chunk_body = [&](auto SB, int kc) {
+                const int kn = (kc + 1 == n_chunks) ? 0 : kc + 1;
+                chunk_t stage[kStage];
+#pragma unroll
+                for (int i = 0; i < kStage; ++i) stage[i] = *q_src(kn, wid * kStage + i);
+                const chunk_t* qb = lds_q + cur * kFrags * kTileChunks;
+#pragma unroll
+                for (int j = 0; j < BKT; ++j) {
+                    // query fragments one group ahead of their MFMAs; the scheduling barriers stop hipcc from
+                    // hoisting all GQ fragment reads (64 VGPRs at GQ = 16) above the MFMA chain, which spills
+                    chunk_t bn = qb[(0 * BKT + j) * kTileChunks + lane];
+#pragma unroll
+                    for (int g = 0; g < GQ; ++g) {
+                        const chunk_t b = bn;
+                        if (g + 1 < GQ) bn = qb[((g + 1) * BKT + j) * kTileChunks + lane];
+#pragma unroll
+                        for (int s = 0; s < RS; ++s) Mfma<STORE>::run(ring[decltype(SB)::value + j][s], b, acc[s][g]);
+                        if (GQ > 8) __builtin_amdgcn_sched_barrier(0);
+                    }
+                    prefetch(decltype(SB)::value + j);
+                }
+                chunk_t* qn = lds_q + (cur ^ 1) * kFrags * kTileChunks;
+#pragma unroll
+                for (int i = 0; i < kStage; ++i) qn[(wid * kStage + i) * kTileChunks + lane] = stage[i];
+                __syncthreads();
+                cur ^= 1;
+            };
+#pragma unroll 1
+            for (int kc = 0; kc < n_chunks; kc += 2) {  // KT is a multiple of 4 -> n_chunks is even
+                chunk_body(std::integral_constant<int, 0>{}, kc);
+                chunk_body(std::integral_constant<int, BKT>{}, kc + 1);
+            }
+            if (live) {
+#pragma unroll
+                for (int s = 0; s < RS; ++s) {
+                    const int64_t row0 = (group * kRowBlocksPerSuper + pair * RS + s) * kRowsPerBlock + quad * 4;
+                    const f32x4_t sc = *reinterpret_cast<const f32x4_t*>(scale + row0);
+                    float ok[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (tail) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int64_t row = row0 + r;
+                            bool v = row < n_rows;
+                            if (v && rowmask) v = (rowmask[row >> 3] >> (row & 7)) & 1;
+                            ok[r] = v ? 1.f : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < GQ; ++g) {
+                        float mr = NEG_INF;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[s][g][r] * sc[r];
+                            v = (ok[r] != 0.f) ? v : NEG_INF;
+                            mr = fmaxf(mr, v);
+                        }
+                        if (NRB == 1) {
+                            mr = fmaxf(mr, __shfl_xor(mr, 16));
+                            mr = fmaxf(mr, __shfl_xor(mr, 32));
+                            if (lane < 16 && 16 * g + lane < nq)
+                                gmax[(int64_t)(16 * g + lane) * gmax_stride + group * kRowBlocksPerSuper + pair * RS + s] = mr;
+                        } else {
+                            m[g] = fmaxf(m[g], mr);
+                        }
+                    }
+                }
+            }
+        }
+        if (NRB != 1 && live) {
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) {
                 float v = m[g];
                 v = fmaxf(v, __shfl_xor(v, 16));
                 v = fmaxf(v, __shfl_xor(v, 32));

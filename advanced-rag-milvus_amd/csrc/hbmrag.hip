@@ -295,6 +295,27 @@ hipError_t launch_scan_g(const hr_index* h, hipStream_t s, int G, const chunk_t*
     }
 }
 
+// Large-batch pass (dense_scan_bigq_kernel): GQ query groups streamed through LDS in k-chunks.
+template <typename STORE, int GQ, int NRB>
+hipError_t launch_scan_bigq(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                            int nq, int64_t n_super) {
+    auto kern = dense_scan_bigq_kernel<STORE, GQ, NRB>;
+    const size_t lds = (size_t)2 * GQ * 2 * 1024;  // 2 buffers x GQ groups x BKT(2) fragments of 1 KiB
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int64_t blocks = std::min<int64_t>((n_super + 7) / 8, (int64_t)h->cu_count);
+    blocks = std::max<int64_t>(blocks, 1);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, h->tiles.as<chunk_t>(), qfrag,
+                       h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
+    return hipGetLastError();
+}
+template <typename STORE>
+hipError_t launch_scan_bigq_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask,
+                              float* gmax, int nq, int64_t n_super) {
+    return group_rows_for(h, h->n_rows) == 16 ? launch_scan_bigq<STORE, 8, 1>(h, s, qfrag, mask, gmax, nq, n_super)
+                                              : launch_scan_bigq<STORE, 8, 4>(h, s, qfrag, mask, gmax, nq, n_super);
+}
+
 int max_groups_for_dim(const hr_index* h) {
     // query tile must fit LDS: G * KT KiB <= 144 KiB
     int g = 156 / std::max(h->KT, 1);
@@ -355,7 +376,10 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     const int GR = group_rows_for(h, h->n_rows);
     const int64_t n_super = (h->n_rows + kSuperRows - 1) / kSuperRows;
     const int64_t n_groups = n_super * (kSuperRows / GR);  // group maxima per query (tail groups hold -inf)
-    const int Gmax = max_groups_for_dim(h);
+    const int Gsmall = max_groups_for_dim(h);
+    // batches beyond what fits LDS whole go through the k-chunked large-batch pass, 128 or 256 queries at a time
+    const bool big = B > 16 * Gsmall && h->KT % 4 == 0 && std::getenv("HBMRAG_NO_BIGQ") == nullptr;
+    const int Gmax = big ? 8 : Gsmall;
     const int chunk_q = 16 * Gmax;
     const size_t qfrag_bytes = (size_t)Gmax * h->KT * 1024;
     HIP_TRY(h, ws->qfrag.ensure(qfrag_bytes));
@@ -368,7 +392,7 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
 
     for (int c0 = 0; (phases & PHASE_SCAN) && c0 < B; c0 += chunk_q) {
         const int nq = std::min(chunk_q, B - c0);
-        const int G = (nq + 15) / 16;
+        const int G = big ? Gmax : (nq + 15) / 16;
         {
             Span sp(h, s, PH_PREP);
             if (h->dtype == HR_F16)
@@ -384,9 +408,15 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
         {
             Span sp(h, s, PH_SCAN);
             float* gm = ws->gmax.as<float>() + (int64_t)c0 * n_groups;
-            hipError_t e = (h->dtype == HR_F16)
-                               ? launch_scan_g<_Float16>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
-                               : launch_scan_g<float>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+            hipError_t e;
+            if (big)
+                e = (h->dtype == HR_F16)
+                        ? launch_scan_bigq_g<_Float16>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
+                        : launch_scan_bigq_g<float>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+            else
+                e = (h->dtype == HR_F16)
+                        ? launch_scan_g<_Float16>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
+                        : launch_scan_g<float>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
             HIP_TRY(h, e);
         }
     }

@@ -1,0 +1,45 @@
+"""Ad-hoc probe (not a test): dense search at B in {64,128,256}, big-batch pass vs multi-pass, + parity on a small corpus."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, "advanced-rag-milvus_amd"); sys.path.insert(0, ".")
+from advanced_rag import _native as nat
+import oracle
+
+# parity first (small corpus, B=200 -> GQ=16; B=100 -> GQ=8)
+rng = np.random.default_rng(0)
+for dt, npdt in ((nat.HR_F16, np.float16), (nat.HR_F32, np.float32)):
+    for n in (5000, 70000):
+        X = rng.standard_normal((n, 256)).astype(np.float32).astype(npdt)
+        h = nat.ShardHandle(256, dt, nat.HR_METRIC_COSINE); h.add_dense(X); h.finalize()
+        for B in (100, 200, 300):
+            Q = rng.standard_normal((B, 256)).astype(np.float32)
+            ids, sc = h.search_dense(Q, 40)
+            oids, osc = oracle.dense_search(X[:, :], Q[:8], 40, oracle.COSINE)
+            oids2, osc2 = oracle.dense_search(X, Q[-4:], 40, oracle.COSINE)
+            ok = np.array_equal(ids[:8], oids) and np.array_equal(sc[:8].view(np.uint32), osc.view(np.uint32)) and np.array_equal(ids[-4:], oids2)
+            print("parity", "f16" if dt == nat.HR_F16 else "f32", n, B, ok, flush=True)
+        h.close()
+
+N, D = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 768
+dev = torch.device("cuda:0")
+h = nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE); h.reserve(N)
+g = torch.Generator(device=dev); g.manual_seed(1)
+for r0 in range(0, N, 500_000):
+    n = min(500_000, N - r0)
+    x = torch.randn((n, D), device=dev, generator=g, dtype=torch.float32).to(torch.float16); torch.cuda.synchronize()
+    h.add_dense_dev(x.data_ptr(), n)
+h.finalize(); h.set_profiling(2)
+st = torch.cuda.current_stream().cuda_stream
+for B in (64, 128, 256):
+    q = torch.randn((B, D), device=dev, generator=g)
+    ids = torch.empty((B, 40), dtype=torch.int64, device=dev); sc = torch.empty((B, 40), dtype=torch.float32, device=dev)
+    fl = torch.empty((B,), dtype=torch.int32, device=dev)
+    for _ in range(3): h.search_dense_dev(q.data_ptr(), B, 40, ids.data_ptr(), sc.data_ptr(), fl.data_ptr(), 0, st)
+    torch.cuda.synchronize(); h.kernel_ms()
+    t0 = time.time()
+    for _ in range(10): h.search_dense_dev(q.data_ptr(), B, 40, ids.data_ptr(), sc.data_ptr(), fl.data_ptr(), 0, st)
+    torch.cuda.synchronize(); dt_ = (time.time() - t0) / 10
+    ms = h.kernel_ms(); scan, launches = ms["dense_scan"]
+    print(f"B={B:3d} total {dt_*1e3:7.3f} ms QPS {B/dt_:9.0f} scan {scan:7.3f} ms x{launches//10} launches = {h.dense_scan_bytes/scan/1e6:7.1f} GB/s/launch | "
+          f"gsel {ms['group_select'][0]:.3f} refine {ms['refine'][0]:.3f} topk {ms['topk'][0]:.3f} exact {int(fl.sum())}/{B}", flush=True)

@@ -152,3 +152,25 @@ def test_concurrent_searches_from_threads(gpu):
         for g in outs:
             assert np.array_equal(w[0], g[0]) and np.array_equal(_bits(w[1]), _bits(g[1]))
     h.close()
+
+
+@pytest.mark.parametrize("dtype,np_dtype", [(nat.HR_F16, np.float16), (nat.HR_F32, np.float32)])
+@pytest.mark.parametrize("n,d,B", [(9000, 256, 65), (9000, 256, 128), (70000, 384, 200), (300, 128, 129)])
+def test_large_batches_take_the_chunked_query_pass(gpu, dtype, np_dtype, n, d, B):
+    """B > 64: the k-chunked large-batch scan (128 queries per pass, queries streamed through LDS) must give
+    the oracle's lists for every query position, including the ragged last pass."""
+    rng = np.random.default_rng(n + B)
+    X = rng.standard_normal((n, d)).astype(np.float32).astype(np_dtype)
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    h = nat.ShardHandle(d, dtype, nat.HR_METRIC_COSINE)
+    h.add_dense(X)
+    h.finalize()
+    ids, sc = h.search_dense(Q, 40)
+    pick = sorted(set([0, 1, 15, 16, 63, 64, 65, 127, B - 1, B // 2]) & set(range(B)))
+    oids, osc = oracle.dense_search(X, Q[pick], 40, nat.HR_METRIC_COSINE)
+    assert np.array_equal(ids[pick], oids) and np.array_equal(_bits(sc[pick]), _bits(osc))
+    mask = np.packbits(rng.random(n) < 0.4, bitorder="little")
+    ids, sc = h.search_dense(Q, 40, mask)
+    oids, osc = oracle.dense_search(X, Q[pick], 40, nat.HR_METRIC_COSINE, mask)
+    assert np.array_equal(ids[pick], oids) and np.array_equal(_bits(sc[pick]), _bits(osc))
+    h.close()
