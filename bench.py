@@ -265,20 +265,6 @@ def main():
     scan_bytes = h.dense_scan_bytes
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
-    # Extra (outside the timed region): the same scan kernel with nothing else on the GPU, to show how
-    # much of the in-region figure is contention from the light stream of the batch in flight.
-    iso_ms = None
-    if rank == 0 or world > 1:
-        one = HybridSearchEngine(h, cfg, device=str(dev)) if n_fly > 1 else eng
-        h.set_profiling(1)
-        for i in range(5):
-            one.h.search_dense_dev(dQ[i % n_batches].data_ptr(), B, kp, one._buffers(B)["ids"][0].data_ptr(),
-                                   one._buffers(B)["scores"][0].data_ptr(), one._buffers(B)["flags"][0].data_ptr(), 0,
-                                   torch.cuda.current_stream(dev).cuda_stream)
-            torch.cuda.synchronize()
-        h.set_profiling(0)
-        iso_ms = h.kernel_ms()["dense_scan"][0]
-
     # ---- p50 latency of single-query retrieve() through the Python API (N=1) --------------------------------
     latency = None
     if world == 1 and not args.no_latency and args.latency_queries > 0:
@@ -328,9 +314,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "dense_scan_bigq_kernel<f16,GQ=8>" if B > 64 else "dense_scan_kernel<f16>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches,
-                         "isolated_launch_ms": iso_ms,
-                         "isolated_achieved": (scan_bytes / (iso_ms * 1e-3) / 1e9) if iso_ms else None},
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches},
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
             "all_lists_proven_exact": flags_exact,
