@@ -309,3 +309,49 @@ def test_engine_resolves_unproven_lists(gpu):
         assert np.array_equal(out["fused_ids"][b, :nf].cpu().numpy(), fused[b][0])
         assert np.array_equal(out["rr_ids"][b, :len(reranked[b][0])].cpu().numpy(), reranked[b][0])
     h.close()
+
+
+def test_config3_1m_768_hybrid_matches_oracle(gpu):
+    """BASELINE config 3: 1M x 768 (bge-base shape) hybrid dense + sparse + RRF (weights 0.7/0.3), 1 GPU.
+    Lists, fused ids and fused scores against the oracle for a few queries of a 64-query batch."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, d, V, nnz, B = 1_000_000, 768, 10000, 100, 64
+
+    def block(b):
+        rng = np.random.default_rng(1234 + b)
+        x = rng.standard_normal((100_000, d), dtype=np.float32).astype(np.float16)
+        idx = ((np.arange(nnz, dtype=np.int32) * (V // nnz))[None, :] + rng.integers(0, V // nnz, (100_000, nnz), dtype=np.int32))
+        val = np.abs(rng.standard_normal((100_000, nnz), dtype=np.float32))
+        return x, idx.reshape(-1), val.reshape(-1)
+
+    with ThreadPoolExecutor(5) as pool:
+        parts = list(pool.map(block, range(10)))
+    X = np.concatenate([p[0] for p in parts])
+    idx = np.concatenate([p[1] for p in parts])
+    val = np.concatenate([p[2] for p in parts])
+    ptr = np.arange(n + 1, dtype=np.int64) * nnz
+    rng = np.random.default_rng(4321)
+    Q = rng.standard_normal((B, d), dtype=np.float32)
+    SQ = [(np.sort(rng.choice(V, nnz, replace=False)).astype(np.int32), np.abs(rng.standard_normal(nnz)).astype(np.float32))
+          for _ in range(B)]
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    h.add_dense(X)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    cfg = EngineConfig(top_k=20)
+    eng = HybridSearchEngine(h, cfg)
+    out = eng.search(torch.from_numpy(Q).cuda(), eng.upload_sparse(pack_sparse_queries(SQ, 0.2)))
+    torch.cuda.synchronize()
+    assert out["flags"].min().item() == 1
+    pick = [0, 31, 63]
+    (di, ds), (si, ss), fused, reranked = oracle_pipeline(X, ptr, idx, val, Q[pick], [SQ[i] for i in pick], cfg)
+    for j, b in enumerate(pick):
+        assert np.array_equal(out["ids"][0, b].cpu().numpy(), di[j]) and np.array_equal(out["ids"][1, b].cpu().numpy(), si[j])
+        assert np.array_equal(out["scores"][0, b].cpu().numpy().view(np.uint32), ds[j].view(np.uint32))
+        assert np.array_equal(out["scores"][1, b].cpu().numpy().view(np.uint32), ss[j].view(np.uint32))
+        fi, fs, _ = fused[j]
+        assert np.array_equal(out["fused_ids"][b].cpu().numpy(), fi)
+        assert np.max(np.abs(out["fused_scores"][b].cpu().numpy() - fs)) <= 1e-4   # north-star tolerance (here: 0)
+        assert np.array_equal(out["fused_scores"][b].cpu().numpy().view(np.uint64), fs.view(np.uint64))
+        assert np.array_equal(out["rr_ids"][b].cpu().numpy(), reranked[j][0])
+    h.close()
