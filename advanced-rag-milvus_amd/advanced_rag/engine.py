@@ -284,6 +284,9 @@ class PipelinedSearchEngine(HybridSearchEngine):
         self.light = t.cuda.Stream(self.device)
         self._slot_bufs = [dict() for _ in range(depth)]
         self._n = 0
+        # optional callable(buffers) run on the light stream after fusion/rerank of every batch, before the
+        # batch is marked done (e.g. a cross-encoder forward over the fused candidates)
+        self.post_hook = None
 
     def _slot(self, slot: int, B: int) -> dict:
         b = self._slot_bufs[slot].get(B)
@@ -317,6 +320,8 @@ class PipelinedSearchEngine(HybridSearchEngine):
                                      kp, slot, b["ids"].data_ptr(), b["scores"].data_ptr(), b["flags"].data_ptr(),
                                      self.light.cuda_stream)
             self._post_lists(b, B, self.light.cuda_stream)
+            if self.post_hook is not None:
+                self.post_hook(b)
             b["done"].record(self.light)
         return b
 

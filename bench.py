@@ -101,6 +101,11 @@ def main():
     ap.add_argument("--block-rows", type=int, default=250_000)
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="rows of the CPU-baseline / parity-gate subsample")
     ap.add_argument("--latency-queries", type=int, default=200)
+    ap.add_argument("--rerank", choices=("learned", "cross-encoder"), default="learned",
+                    help="learned = LearnedRanker's linear score (the reference's deterministic rerank branch, HIP kernel); "
+                         "cross-encoder = additionally run a random-init MiniLM-L6 cross-encoder (PyTorch-ROCm) over the "
+                         "top_k fused candidates of every query and keep its best rerank_top_k (BASELINE config 4's '20->5')")
+    ap.add_argument("--ce-seq-len", type=int, default=128)
     ap.add_argument("--no-sparse", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -228,10 +233,43 @@ def main():
             sys.exit(2)
 
     # ---- timed region -----------------------------------------------------------------------------------
+    ce_note = None
+    if args.rerank == "cross-encoder":
+        from advanced_rag.encoders import CrossEncoderModel
+        ce = CrossEncoderModel(device=str(dev), max_len=args.ce_seq_len)
+        T, vocab = args.ce_seq_len, ce.config.vocab_size
+        pos = torch.arange(T, device=dev, dtype=torch.int64)[None, None, :]
+        types = torch.zeros((B * args.top_k, T), dtype=torch.long, device=dev)
+        types[:, T // 4:] = 1
+        mask = torch.ones((B * args.top_k, T), dtype=torch.bool, device=dev)
+        ce_out = {}
+
+        def cross_encode(b):
+            # synthetic token ids derived from (query slot, fused doc id, position): there is no text behind the
+            # random corpus; the forward pass (the cost being measured) does not depend on what the tokens are
+            doc = b["fused_ids"].clamp_min(0)[:, :, None]
+            toks = (1000 + (doc * 7919 + pos * 104729 + torch.arange(B, device=dev)[:, None, None] * 31) % (vocab - 1000))
+            toks = toks.view(B * args.top_k, T)
+            toks[:, 0] = 101
+            with torch.inference_mode():
+                scores = ce.module(toks, types, mask).view(B, args.top_k)
+            scores = scores.masked_fill(b["fused_ids"] < 0, float("-inf"))
+            top = torch.topk(scores, cfg.rerank_top_k, dim=1)
+            b["ce_ids"] = torch.gather(b["fused_ids"], 1, top.indices)
+            b["ce_scores"] = top.values
+
+        ce_note = (f"+ cross-encoder rerank {args.top_k}->{cfg.rerank_top_k}: random-init MiniLM-L6-H384 (PyTorch-ROCm, fp16), "
+                   f"{B * args.top_k} pairs x {T} tokens per step")
+        if n_fly > 1:
+            eng.post_hook = cross_encode
+
     def step(i):
         if n_fly > 1:
             return eng.submit(dQ[i % n_batches], dS[i % n_batches])
-        return eng.search(dQ[i % n_batches], dS[i % n_batches])
+        out = eng.search(dQ[i % n_batches], dS[i % n_batches])
+        if args.rerank == "cross-encoder":
+            cross_encode(out)
+        return out
 
     for i in range(args.warmup):
         step(i)
@@ -307,7 +345,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{N}x{D} fp16 COSINE corpus" + (f" + sparse {SPARSE_NNZ}nnz/{SPARSE_DIM}d" if use_sparse else "")
                        + f", hybrid dense+sparse k'={kp} -> RRF(k=60, 0.7/0.3) top_k={args.top_k} -> learned-ranker rerank "
-                       f"{args.top_k}->{cfg.rerank_top_k}, batch {B} queries/step (BASELINE config 4 without the cross-encoder forward)",
+                       f"{args.top_k}->{cfg.rerank_top_k}, batch {B} queries/step "
+                       + (ce_note if ce_note else "(BASELINE config 4 without the cross-encoder forward)"),
                        "rows": N, "dim": D, "batch": B, "top_k": args.top_k, "k_prime": kp,
                        "batches_in_flight": n_fly,
                        "parallelism": f"row-sharded x{world}, one RCCL all-gather of per-shard top-k' per step" if world > 1 else "single GPU"},
