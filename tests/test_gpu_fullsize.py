@@ -130,3 +130,66 @@ def test_fullsize_rowmask_monotone(shards):
         kept = [i for i in ids[j].tolist() if allow[i]]
         assert mids[j, :len(kept)].tolist()[:40] == kept[:40]
         assert not (~allow[mids[j]]).any()
+
+
+def test_large_sparse_properties(gpu):
+    """Sparse path at 2M docs (123 doc ranges): spot oracle on returned docs (bit for bit) and on sampled outsiders,
+    batch-position invariance, two-shard merge == whole, every list proven exact."""
+    n, V, nnz, B, K = 2_000_000, 10000, 50, 48, 40
+    rng = np.random.default_rng(77)
+    stride = V // nnz
+    idx = ((np.arange(nnz, dtype=np.int32) * stride)[None, :] + rng.integers(0, stride, (n, nnz), dtype=np.int32)).reshape(-1)
+    val = np.abs(rng.standard_normal(n * nnz, dtype=np.float32))
+    ptr = np.arange(n + 1, dtype=np.int64) * nnz
+    queries = [(np.sort(rng.choice(V, 100, replace=False)).astype(np.int32), np.abs(rng.standard_normal(100)).astype(np.float32))
+               for _ in range(B)]
+    whole = nat.ShardHandle(0, sparse_dim=V)
+    whole.add_sparse(ptr, idx, val)
+    whole.finalize()
+    ids, sc = whole.search_sparse(queries, K, 0.2)
+    assert (ids >= 0).all() and (np.diff(sc, axis=1) <= 0).all()
+    ties = np.diff(sc, axis=1) == 0
+    assert (np.diff(ids, axis=1)[ties] > 0).all()
+    for j in (0, 17, B - 1):   # spot oracle
+        qi, qv = oracle.drop_query(*queries[j], 0.2)
+        rows = ids[j]
+        sub_ptr = np.arange(K + 1, dtype=np.int64) * nnz
+        sub_idx = np.concatenate([idx[r * nnz:(r + 1) * nnz] for r in rows])
+        sub_val = np.concatenate([val[r * nnz:(r + 1) * nnz] for r in rows])
+        want = oracle.sparse_scores(sub_ptr, sub_idx, sub_val, qi, qv)
+        assert np.array_equal(want.view(np.uint32), sc[j].view(np.uint32))
+        out = rng.integers(0, n, 200_000)
+        out = out[~np.isin(out, rows)]
+        o_ptr = np.arange(len(out) + 1, dtype=np.int64) * nnz
+        o_idx = idx.reshape(n, nnz)[out].reshape(-1)
+        o_val = val.reshape(n, nnz)[out].reshape(-1)
+        assert oracle.sparse_scores(o_ptr, o_idx, o_val, qi, qv).max() <= sc[j, -1]
+        i1, s1 = whole.search_sparse([queries[j]], K, 0.2)
+        assert np.array_equal(i1[0], ids[j]) and np.array_equal(s1[0].view(np.uint32), sc[j].view(np.uint32))
+    # two shards + merge
+    from advanced_rag.engine import pack_sparse_queries
+    half = n // 2
+    p, i_, v_, mx = pack_sparse_queries(queries, 0.2)
+    dp, di_, dv_ = (torch.from_numpy(a).cuda() for a in (p, i_, v_))
+    gs = torch.empty((2, B, K), dtype=torch.float32, device="cuda")
+    gi = torch.empty((2, B, K), dtype=torch.int64, device="cuda")
+    fl = torch.zeros((2, B), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    shards = []
+    for r in range(2):
+        h = nat.ShardHandle(0, sparse_dim=V)
+        h.set_row_offset(r * half)
+        lo, hi = r * half, (r + 1) * half
+        h.add_sparse(ptr[lo:hi + 1] - ptr[lo], idx[ptr[lo]:ptr[hi]], val[ptr[lo]:ptr[hi]])
+        h.finalize()
+        h.search_sparse_dev(dp.data_ptr(), di_.data_ptr(), dv_.data_ptr(), B, len(i_), mx, K, gi[r].data_ptr(), gs[r].data_ptr(),
+                            fl[r].data_ptr(), 0, st)
+        shards.append(h)
+    mi = torch.empty((B, K), dtype=torch.int64, device="cuda")
+    ms = torch.empty((B, K), dtype=torch.float32, device="cuda")
+    nat.merge_topk_dev(gs.data_ptr(), gi.data_ptr(), 2, B, K, K, mi.data_ptr(), ms.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert int(fl.min()) == 1
+    assert np.array_equal(mi.cpu().numpy(), ids) and np.array_equal(ms.cpu().numpy().view(np.uint32), sc.view(np.uint32))
+    for h in shards + [whole]:
+        h.close()
