@@ -95,7 +95,8 @@ class ShardCollection:
 class MilvusIndexManager:
     def __init__(self, host: str = "localhost", port: int = 19530, enable_sharding: bool = True, num_shards: int = 4,
                  semantic_dim: int = 1536, sparse_dim: int = 10000, domain_dim: int = 768, connect: bool = True,
-                 *, dtype: str = "float16", device: int = 0, enable_domain: bool = True):
+                 *, dtype: str = "float16", device: int = 0, enable_domain: bool = True,
+                 device_embedding_cache: int = 0):
         self.host, self.port = host, port
         self.enable_sharding, self.num_shards = enable_sharding, num_shards
         self.semantic_dim, self.sparse_dim, self.domain_dim = semantic_dim, sparse_dim, domain_dim
@@ -112,6 +113,11 @@ class MilvusIndexManager:
         self._np_cols: Optional[Dict[str, np.ndarray]] = None
         self._deleted: Optional[np.ndarray] = None
         self._synthetic_rows = 0   # rows whose payload is derived from the row number (bulk/benchmark ingest)
+        # "embedding cache -> device-resident tensor": with device_embedding_cache=N > 0 the semantic QUERY
+        # embeddings are kept in one [N, dim] HBM tensor; a hit hands the search kernel a device pointer
+        # (no host hop), a miss encodes once (on the device when the generator offers encode_to_device).
+        self._dev_cache_slots = int(device_embedding_cache)
+        self._dev_cache = None
         if connect:
             self._connect()
             self._initialize_collections()
@@ -390,10 +396,30 @@ class MilvusIndexManager:
             idx, val = self._as_sparse_payload(query_embedding)
             drop = float((params.get("params") or {}).get("drop_ratio_search", 0.0))
             ids, sc = coll.handle.search_sparse([(idx, val)], top_k, drop, mask)
+        elif hasattr(query_embedding, "is_cuda") and query_embedding.is_cuda and mask is None:
+            ids, sc = self._search_dense_device(coll.handle, query_embedding, top_k)
         else:
+            if hasattr(query_embedding, "detach"):
+                query_embedding = query_embedding.detach().cpu().numpy()
             q = np.asarray(query_embedding, dtype=np.float32).reshape(1, -1)
             ids, sc = coll.handle.search_dense(q, top_k, mask)
         return self._format_hits(ids[0], sc[0])
+
+    @staticmethod
+    def _search_dense_device(handle, q_dev, top_k: int):
+        """Query already in HBM (device-resident embedding cache): device form, no upload; an unproven
+        list (ties at the candidate cut) is redone through the host form."""
+        import torch
+        q = q_dev.reshape(1, -1).to(torch.float32).contiguous()
+        ids = torch.empty((1, top_k), dtype=torch.int64, device=q.device)
+        sc = torch.empty((1, top_k), dtype=torch.float32, device=q.device)
+        flag = torch.zeros((1,), dtype=torch.int32, device=q.device)
+        stream = torch.cuda.current_stream(q.device)
+        handle.search_dense_dev(q.data_ptr(), 1, top_k, ids.data_ptr(), sc.data_ptr(), flag.data_ptr(), 0, stream.cuda_stream)
+        stream.synchronize()
+        if int(flag.item()) != 1:
+            return handle.search_dense(q.cpu().numpy(), top_k)
+        return ids.cpu().numpy(), sc.cpu().numpy()
 
     async def search(self, query_embedding, collection_name: str, top_k: int = 20, filters: Optional[str] = None,
                      search_params: Optional[Dict] = None) -> List[Dict[str, Any]]:
@@ -458,7 +484,32 @@ class MilvusIndexManager:
                 out[i] = np.random.randn(self.semantic_dim).astype(np.float32)
         return out  # type: ignore[return-value]
 
-    async def _generate_semantic_embedding(self, text: str) -> np.ndarray:
+    def _device_query_embedding(self, text: str):
+        """float32 [dim] CUDA tensor for `text` from the device-resident table (filled on a miss)."""
+        from .embedding_cache import DeviceEmbeddingTable, EmbeddingCache
+        if self._dev_cache is None:
+            self._dev_cache = DeviceEmbeddingTable(self._dev_cache_slots, self.semantic_dim, f"cuda:{self.device}")
+            self.device_cache_stats = {"hits": 0, "misses": 0}
+        key = EmbeddingCache._materialize_key(text)
+        vec = self._dev_cache.lookup(key)
+        if vec is not None:
+            self.device_cache_stats["hits"] += 1
+            return vec
+        self.device_cache_stats["misses"] += 1
+        gen = self.embedding_generator
+        if gen is not None and hasattr(gen, "encode_to_device"):
+            fresh = gen.encode_to_device([text])[0]
+        elif gen is not None:
+            fresh = np.asarray(gen.encode_semantic(text), dtype=np.float32)
+        else:
+            fresh = np.random.randn(self.semantic_dim).astype(np.float32)
+        return self._dev_cache.store(key, fresh)
+
+    async def _generate_semantic_embedding(self, text: str):
+        if self._dev_cache_slots > 0 and self._main is not None and not (
+                self.embedding_generator is not None and asyncio.iscoroutinefunction(self.embedding_generator.encode_semantic)):
+            return await asyncio.get_event_loop().run_in_executor(self.embedding_executor, self._device_query_embedding, text)
+
         async def compute() -> np.ndarray:
             if self.embedding_generator:
                 return await self._run_encoder(self.embedding_generator.encode_semantic, text)

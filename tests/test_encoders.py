@@ -89,3 +89,48 @@ def test_encoders_drive_the_pipeline_on_gpu(gpu):
     finally:
         RetrievalConstants.TIMEOUT_SECONDS = old
         asyncio.run(p.close())
+
+
+@pytest.mark.gpu
+def test_device_resident_query_embedding_cache(gpu):
+    """north star: 'embedding cache -> device-resident tensor'.  Query embeddings live in one HBM table; a hit is a
+    device pointer handed to the search kernel, and results equal the host-embedding path."""
+    from advanced_rag import HybridRetriever, MilvusIndexManager, RetrievalConfig
+    from advanced_rag.constants import RetrievalConstants
+    from advanced_rag.bm25 import BM25SparseEncoder
+    texts = [f"passage number {i} about thing{i % 11}" for i in range(500)]
+    bm25 = BM25SparseEncoder(sparse_dim=512).fit(texts)
+    enc = SentenceEncoder(TINY, device="cuda:0", dtype=torch.float32, seed=5, sparse_encoder=bm25)
+    X = np.stack(enc.encode_semantic_batch(texts))
+    rows = [bm25.encode_document(t) for t in texts]
+    indptr = np.cumsum([0] + [len(r["indices"]) for r in rows]).astype(np.int64)
+    docs_sparse = (indptr, np.concatenate([r["indices"] for r in rows]).astype(np.int32),
+                   np.concatenate([r["values"] for r in rows]).astype(np.float32))
+    plain = MilvusIndexManager(semantic_dim=64, sparse_dim=512, enable_domain=False)
+    cached = MilvusIndexManager(semantic_dim=64, sparse_dim=512, enable_domain=False, device_embedding_cache=8)
+    for m in (plain, cached):
+        m.embedding_generator = enc
+        m.add_rows(X, docs_sparse, ids=[f"t{i}" for i in range(500)], contents=texts)
+        m.finalize()
+    old = RetrievalConstants.TIMEOUT_SECONDS
+    RetrievalConstants.TIMEOUT_SECONDS = 60.0
+    try:
+        q = "passage about thing3"
+        emb = asyncio.run(cached._generate_semantic_embedding(q))
+        assert emb.is_cuda and emb.shape == (64,)
+        assert asyncio.run(cached._generate_semantic_embedding(q)).data_ptr() == emb.data_ptr()   # same HBM slot
+        assert cached.device_cache_stats == {"hits": 1, "misses": 1}
+        a = asyncio.run(plain.search(asyncio.run(plain._generate_semantic_embedding(q)), "semantic_index", 10))
+        b = asyncio.run(cached.search(emb, "semantic_index", 10))
+        assert [h["id"] for h in a] == [h["id"] for h in b]
+        assert np.allclose([h["score"] for h in a], [h["score"] for h in b], atol=1e-6)
+        for i in range(12):                                   # FIFO eviction beyond 8 slots
+            asyncio.run(cached._generate_semantic_embedding(f"query {i}"))
+        assert len(cached._dev_cache._slots) == 8
+        out = asyncio.run(HybridRetriever(cached, RetrievalConfig(top_k=5)).retrieve(q, profile_hint="default"))
+        ref = asyncio.run(HybridRetriever(plain, RetrievalConfig(top_k=5)).retrieve(q, profile_hint="default"))
+        assert [h["id"] for h in out] == [h["id"] for h in ref] and len(out) == 5
+    finally:
+        RetrievalConstants.TIMEOUT_SECONDS = old
+        asyncio.run(plain.close())
+        asyncio.run(cached.close())
