@@ -344,9 +344,10 @@ def main():
             "n_gpus": world, **({"rehearsal_single_gpu_gloo": True} if rehearsal else {}), "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"{N}x{D} fp16 COSINE corpus" + (f" + sparse {SPARSE_NNZ}nnz/{SPARSE_DIM}d" if use_sparse else "")
-                       + f", hybrid dense+sparse k'={kp} -> RRF(k=60, 0.7/0.3) top_k={args.top_k} -> learned-ranker rerank "
-                       f"{args.top_k}->{cfg.rerank_top_k}, batch {B} queries/step "
-                       + (ce_note if ce_note else "(BASELINE config 4 without the cross-encoder forward)"),
+                       + (f", hybrid dense+sparse k'={kp} -> RRF(k=60, 0.7/0.3)" if use_sparse else f", dense only k'={kp} -> RRF(k=60) of the one list")
+                       + f" top_k={args.top_k} -> learned-ranker rerank {args.top_k}->{cfg.rerank_top_k}, batch {B} queries/step "
+                       + (ce_note if ce_note else ("(BASELINE config 4 without the cross-encoder forward)" if (N, D) == (10_000_000, 768) and use_sparse
+                                                   else "(BASELINE config 5 on one GPU)" if (N, D, B, use_sparse) == (50_000_000, 1024, 256, False) else "")),
                        "rows": N, "dim": D, "batch": B, "top_k": args.top_k, "k_prime": kp,
                        "batches_in_flight": n_fly,
                        "parallelism": f"row-sharded x{world}, one RCCL all-gather of per-shard top-k' per step" if world > 1 else "single GPU"},
