@@ -61,6 +61,25 @@ class BM25SparseEncoder:
     def merge_stats(self, n_docs: int, total_len: int, df: np.ndarray) -> None:
         self.n_docs, self.total_len, self.df = int(n_docs), int(total_len), np.asarray(df, dtype=np.int64).copy()
 
+    def all_reduce_stats(self, dist=None, group=None, device: str = "cpu") -> "BM25SparseEncoder":
+        """Row-sharded ingest: every rank observed only its own documents, but idf and avgdl must be
+        those of the whole corpus (SURVEY.md §8e "global statistics").  One SUM all-reduce of
+        [n_docs, total_len, df[0..V)] (int64; `device` = "cuda:N" for the RCCL backend, "cpu" for gloo),
+        after which every rank encodes documents and queries with identical weights."""
+        import torch
+        if dist is None:
+            import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return self
+        buf = torch.empty(2 + self.sparse_dim, dtype=torch.int64)
+        buf[0], buf[1] = self.n_docs, self.total_len
+        buf[2:] = torch.from_numpy(self.df)
+        buf = buf.to(device)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        host = buf.cpu().numpy()
+        self.merge_stats(int(host[0]), int(host[1]), host[2:])
+        return self
+
     # -- vectors --------------------------------------------------------------------
     @staticmethod
     def _payload(weights: Dict[int, float]) -> Dict[str, List]:

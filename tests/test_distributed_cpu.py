@@ -86,6 +86,16 @@ def _worker(rank, world, port, ret):
             assert np.array_equal(got_s.view(np.uint32), want_s.view(np.uint32))
         assert set(gd[0][0, :2].tolist()) == {100, 4000}  # the tie pair spans both shards, lower id first
         assert gd[0][0, 0] == 100
+        # global BM25 statistics: each rank observes its own documents, one all-reduce makes idf/avgdl global
+        from advanced_rag.bm25 import BM25SparseEncoder
+        docs = [f"doc {i} token{i % 7} shared words here {'extra ' * (i % 3)}" for i in range(41)]
+        dlo, dhi = shard_range(len(docs), rank, world, align=1)
+        local = BM25SparseEncoder(sparse_dim=257).fit(docs[dlo:dhi]).all_reduce_stats(dist)
+        whole = BM25SparseEncoder(sparse_dim=257).fit(docs)
+        assert (local.n_docs, local.total_len) == (whole.n_docs, whole.total_len)
+        assert np.array_equal(local.df, whole.df)
+        assert local.encode_query("token3 shared missing") == whole.encode_query("token3 shared missing")
+        assert local.encode_document(docs[5]) == whole.encode_document(docs[5])
         ret[rank] = True
     finally:
         dist.destroy_process_group()
