@@ -481,7 +481,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     for (int q0 = 0; (phases & PHASE_SCAN) && q0 < B; q0 += 32768) {  // gridDim.y limit
         const int nq = std::min(32768, B - q0);
         Span sp(h, s, PH_SSCAN);
-        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(1024), 0, s,
+        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(kScanThreads), 0, s,
                            h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(),
                            h->post.as<uint32_t>(), ws->pq_n.as<int32_t>() + q0,
                            ws->pq_idx.as<int32_t>() + (int64_t)q0 * stride, ws->pq_w.as<float>() + (int64_t)q0 * stride,
@@ -1370,6 +1370,13 @@ int hr_set_profiling(hr_index* h, int enabled) {
     return HR_OK;
 }
 
+#ifdef HR_TRACE
+HR_API int hr_debug_trace(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hbmrag::hr_trace), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hbmrag::hr_trace), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 int hr_last_kernel_ms(hr_index* h, float* out_ms, int n) {
     if (!h || !out_ms || n < 2 * PH_COUNT) return fail(h, HR_EINVAL, "need room for %d floats", 2 * PH_COUNT);
     DeviceGuard dg(h->device);

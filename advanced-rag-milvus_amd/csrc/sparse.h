@@ -150,11 +150,15 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
 // the range is applied with an LDS integer atomic, and only the per-64-doc
 // maxima leave the CU.  Work is cut into items of kItemPostings consecutive
 // postings of one run; each wave takes items in a strided loop, kItemsInFlight
-// at a time, so it keeps 8 independent coalesced loads in flight instead of one.
+// at a time, so it keeps 16 independent coalesced loads in flight instead of one
+// (a typical (query, range) — 80 runs of ~164 postings = ~240 items — is then ONE round trip).
 // Algorithmic HBM bytes per (query, range): sum over query terms of run_len * 4
 // (packed uint16 doc + fp16 weight) + 2*4 per term for the run bounds + group maxima out.
+constexpr int kScanThreads = 1024;
+constexpr int kDocsPerThread = kRangeDocs / kScanThreads;  // consecutive docs one thread reduces in the group-max pass (16 or 32)
+constexpr int kScanWaves = kScanThreads / 64;
 constexpr int kItemPostings = 64;
-constexpr int kItemsInFlight = 8;
+constexpr int kItemsInFlight = 16;
 constexpr int kItemTable = 4096;  // items whose run is looked up from a table instead of searched
 
 __device__ inline int fixed_contrib(float p) {  // round away from zero, branch-free
@@ -165,7 +169,15 @@ __device__ inline int fixed_contrib(float p) {  // round away from zero, branch-
 // thread per 16 docs, stride 17 words) then read conflict-free.
 __device__ inline int acc_index(int d) { return d + (d >> 4); }
 
-__global__ __launch_bounds__(1024) void sparse_scan_kernel(
+#ifdef HR_TRACE
+__device__ unsigned long long hr_trace[16];
+#define TR(i) do { if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&hr_trace[i], t_ - tr_last); tr_last = t_; } } while (0)
+#define TRWAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#else
+#define TR(i)
+#define TRWAIT()
+#endif
+__global__ __launch_bounds__(kScanThreads) void sparse_scan_kernel(
     const unsigned int* __restrict__ rt_off, int64_t V1, const int64_t* __restrict__ range_base,
     const uint32_t* __restrict__ post,
     const int32_t* __restrict__ pq_n, const int32_t* __restrict__ pq_idx, const float* __restrict__ pq_w,
@@ -180,10 +192,15 @@ __global__ __launch_bounds__(1024) void sparse_scan_kernel(
     const int64_t range = blockIdx.x;
     const int qi = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef HR_TRACE
+    unsigned long long tr_last = __builtin_amdgcn_s_memtime();
+    if (tid == 0) atomicAdd(&hr_trace[15], 1ull);
+#endif
     {
         int4* a4 = reinterpret_cast<int4*>(acc);
-        for (int i = tid; i < (kRangeDocs + kRangeDocs / 16) / 4; i += 1024) a4[i] = make_int4(0, 0, 0, 0);
+        for (int i = tid; i < (kRangeDocs + kRangeDocs / 16) / 4; i += kScanThreads) a4[i] = make_int4(0, 0, 0, 0);
     }
+    TRWAIT(); TR(0);
     const unsigned int* offs = rt_off + range * V1;
     const uint32_t* pp = post + range_base[range];
     // every load below is independent of the others except run bounds <- term: two round trips, not three
@@ -197,16 +214,12 @@ __global__ __launch_bounds__(1024) void sparse_scan_kernel(
         const bool slot = tid < kScanTermChunk && tc + tid < stride;
         const int32_t t = slot ? my_idx[tc + tid] : 0;
         const float wq = slot ? my_w[tc + tid] : 0.f;
+        TRWAIT(); TR(1);
         const unsigned int lo = slot ? offs[t] : 0u, hi = slot ? offs[t + 1] : 0u;
         const int nt = min(kScanTermChunk, max(n_terms - tc, 0));
-        __syncthreads();
-        unsigned int items = 0;
-        if (tid < nt) {
-            run_lo[tid] = lo;
-            run_hi[tid] = hi;
-            run_w[tid] = wq;
-            items = (hi - lo + kItemPostings - 1) / kItemPostings;
-        }
+        TRWAIT(); TR(2);
+        if (tc) __syncthreads();  // the run tables of the previous chunk are still being read
+        const unsigned int items = tid < nt ? (hi - lo + kItemPostings - 1) / kItemPostings : 0u;
         // exclusive scan of `items` over the first 256 threads (4 waves)
         unsigned int x = items;
 #pragma unroll
@@ -219,79 +232,92 @@ __global__ __launch_bounds__(1024) void sparse_scan_kernel(
         if (tid < kScanTermChunk) {
             unsigned int wbase = 0;
             for (int j = 0; j < wave; ++j) wbase += wsum[j];
-            item_pre[tid] = wbase + x - items;
+            const unsigned int first = wbase + x - items;
+            item_pre[tid] = first;
             if (tid == kScanTermChunk - 1) item_pre[kScanTermChunk] = wbase + x;
+            if (tid < nt) {
+                run_lo[tid] = lo;
+                run_hi[tid] = hi;
+                run_w[tid] = wq;
+                // run of each of the first kItemTable items
+                for (unsigned int c = 0; c < items && first + c < kItemTable; ++c) item_run[first + c] = (uint8_t)tid;
+            }
         }
         __syncthreads();
         const unsigned int total_items = item_pre[kScanTermChunk];
-        if (tid < nt) {  // run of each of the first kItemTable items
-            const unsigned int first = item_pre[tid];
-            for (unsigned int c = 0; c < items && first + c < kItemTable; ++c) item_run[first + c] = (uint8_t)tid;
-        }
-        __syncthreads();
+        TR(3);
 
-        for (unsigned int base = wave; base < total_items; base += 16 * kItemsInFlight) {
-            unsigned int e[kItemsInFlight];
-            bool ok[kItemsInFlight];
-            float w[kItemsInFlight];
+        for (unsigned int base = wave; base < total_items; base += kScanWaves * kItemsInFlight) {
+            uint32_t pk[kItemsInFlight];
+            int rr[kItemsInFlight];
 #pragma unroll
-            for (int u = 0; u < kItemsInFlight; ++u) {
-                const unsigned int item = base + 16 * u;
-                ok[u] = false;
-                e[u] = 0;
-                w[u] = 0.f;
+            for (int u = 0; u < kItemsInFlight; ++u) {  // every load is issued before the first use
+                const unsigned int item = base + kScanWaves * u;
+                rr[u] = 0;
+                pk[u] = 0u;
                 if (item < total_items) {
-                    int lo;
+                    int r;
                     if (item < kItemTable) {
-                        lo = item_run[item];
+                        r = item_run[item];
                     } else {  // largest r with item_pre[r] <= item (wave-uniform)
-                        lo = 0;
-                        int hi = nt - 1;
-                        while (lo < hi) {
-                            const int mid = (lo + hi + 1) >> 1;
-                            if (item_pre[mid] <= item) lo = mid; else hi = mid - 1;
+                        r = 0;
+                        int top = nt - 1;
+                        while (r < top) {
+                            const int mid = (r + top + 1) >> 1;
+                            if (item_pre[mid] <= item) r = mid; else top = mid - 1;
                         }
                     }
-                    e[u] = run_lo[lo] + (item - item_pre[lo]) * kItemPostings + lane;
-                    ok[u] = e[u] < run_hi[lo];
-                    w[u] = run_w[lo];
+                    const unsigned int e = run_lo[r] + (item - item_pre[r]) * kItemPostings + lane;
+                    rr[u] = r;
+                    if (e < run_hi[r]) pk[u] = pp[e];
                 }
             }
-            uint32_t pk[kItemsInFlight];
+            TRWAIT(); TR(4);
 #pragma unroll
-            for (int u = 0; u < kItemsInFlight; ++u)  // every load is issued before the first use
-                pk[u] = ok[u] ? pp[e[u]] : 0u;
-#pragma unroll
-            for (int u = 0; u < kItemsInFlight; ++u)
-                if (ok[u]) atomicAdd(&acc[acc_index((int)(pk[u] & 0xFFFFu))], fixed_contrib(w[u] * posting_weight(pk[u])));
+            for (int u = 0; u < kItemsInFlight; ++u)  // weight bits 0 = no posting (or a zero weight): nothing to add
+                if (pk[u] >> 16) atomicAdd(&acc[acc_index((int)(pk[u] & 0xFFFFu))], fixed_contrib(run_w[rr[u]] * posting_weight(pk[u])));
         }
     }
+    TRWAIT(); TR(5);
     __syncthreads();
+    TR(6);
     // per-group maxima: every thread reduces 16 consecutive docs; 64-doc groups
     // finish with a 4-lane reduction
     {
-        int m = 0;
-        const int64_t doc0 = range * kRangeDocs + (int64_t)tid * 16;
+        int m[kDocsPerThread / 16];
+        const int64_t doc0 = range * kRangeDocs + (int64_t)tid * kDocsPerThread;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            int v = acc[acc_index(tid * 16 + j)];
-            if (rowmask) {
-                const int64_t dd = doc0 + j;
-                if (dd < n_docs && !((rowmask[dd >> 3] >> (dd & 7)) & 1)) v = 0;
+        for (int c = 0; c < kDocsPerThread / 16; ++c) {
+            m[c] = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int v = acc[acc_index(tid * kDocsPerThread + c * 16 + j)];
+                if (rowmask) {
+                    const int64_t dd = doc0 + c * 16 + j;
+                    if (dd < n_docs && !((rowmask[dd >> 3] >> (dd & 7)) & 1)) v = 0;
+                }
+                m[c] = max(m[c], v);
             }
-            m = max(m, v);
         }
         const float inv = scale > 0.f ? 1.0f / scale : 0.f;
         if (group_docs == 16) {
-            const int64_t group = range * (kRangeDocs / 16) + tid;
-            if (group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)m * inv;
+#pragma unroll
+            for (int c = 0; c < kDocsPerThread / 16; ++c) {
+                const int64_t group = range * (kRangeDocs / 16) + tid * (kDocsPerThread / 16) + c;
+                if (group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)m[c] * inv;
+            }
         } else {
-            m = max(m, __shfl_xor(m, 1));
-            m = max(m, __shfl_xor(m, 2));
-            const int64_t group = range * (kRangeDocs / 64) + (tid >> 2);
-            if ((tid & 3) == 0 && group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)m * inv;
+            int mm = m[0];
+#pragma unroll
+            for (int c = 1; c < kDocsPerThread / 16; ++c) mm = max(mm, m[c]);
+            constexpr int kLanesPerGroup = 64 / kDocsPerThread;  // 4 or 2
+#pragma unroll
+            for (int off = 1; off < kLanesPerGroup; off <<= 1) mm = max(mm, __shfl_xor(mm, off));
+            const int64_t group = range * (kRangeDocs / 64) + tid / kLanesPerGroup;
+            if (tid % kLanesPerGroup == 0 && group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)mm * inv;
         }
     }
+    TRWAIT(); TR(7);
 }
 
 // ---- refine: one thread per candidate doc (group_docs = 16 or 64 docs per group) ----
