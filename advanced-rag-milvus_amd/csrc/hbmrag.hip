@@ -496,9 +496,10 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     }
     {
         Span sp(h, s, PH_SREFINE);
-        hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 255) / 256, B), dim3(256), 0, s,
-                           h->s_indptr.as<int64_t>(), h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx,
-                           d_qval, d_mask, ws->cand.as<int32_t>(), C, GR, h->n_sparse, ws->cscore.as<float>(),
+        hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 255) / 256, B), dim3(256),
+                           (size_t)kFilterBits / 8 + (size_t)stride * 8, s, h->s_indptr.as<int64_t>(),
+                           h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
+                           ws->cand.as<int32_t>(), C, GR, h->n_sparse, stride, ws->cscore.as<float>(),
                            ws->crow.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
     }

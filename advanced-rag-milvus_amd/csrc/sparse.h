@@ -320,27 +320,39 @@ __global__ __launch_bounds__(kScanThreads) void sparse_scan_kernel(
     TRWAIT(); TR(7);
 }
 
-// ---- refine: one thread per candidate doc (group_docs = 16 or 64 docs per group) ----
+// ---- refine: one WAVE per candidate doc at a time (group_docs = 16 or 64 docs per group) ----
 // Canonical score: walk the doc's CSR entries in stored order, look each index
 // up in the query's sorted terms, accumulate exact products in fp64.
 // Restated in oracle/oracle.c:oracle_sparse_scores().
-// The block (4 waves = 4 candidate groups of one query) stages the query in LDS
+// The block (4 waves x 64 candidate docs of one query) stages the query in LDS
 // together with a 32768-bit hashed membership filter, so the ~99 % of entries
 // that cannot match cost one LDS read instead of a binary search.
+// Each wave walks its 64 docs one after the other with lane = entry: the doc's indices
+// and values arrive as two coalesced loads per 64 entries (the entries of the next
+// kRefinePrefetch docs are already in flight), every lane tests its own entry, and the
+// few matching products are added in ENTRY ORDER (ballot, lowest lane first), which is
+// the canonical order.  (One thread per doc, the first form of this kernel, read each
+// row with a 400-byte stride between lanes and thrashed the L1: 0.97 ms per 128-query
+// batch against the scans it shares the chip with.)
 constexpr int kFilterBits = 32768;
+constexpr int kRefinePrefetch = 2;
 
 __global__ __launch_bounds__(256) void refine_sparse_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
     const float* __restrict__ q_val, const uint8_t* __restrict__ rowmask,
-    const int32_t* __restrict__ cand, int C, int group_docs, int64_t n_docs, float* __restrict__ out_score,
-    int32_t* __restrict__ out_row) {
-    __shared__ int32_t s_idx[HR_MAX_QUERY_NNZ];
-    __shared__ float s_val[HR_MAX_QUERY_NNZ];
-    __shared__ unsigned int s_filter[kFilterBits / 32];
-    const int qi = blockIdx.y, tid = threadIdx.x;
+    const int32_t* __restrict__ cand, int C, int group_docs, int64_t n_docs, int q_cap,
+    float* __restrict__ out_score, int32_t* __restrict__ out_row) {
+    // dynamic LDS: filter words, then q_cap query indices and q_cap query values (q_cap = the batch's
+    // longest query rounded up, so short queries leave the CU room for many blocks)
+    extern __shared__ unsigned int refine_lds[];
+    unsigned int* s_filter = refine_lds;
+    int32_t* s_idx = reinterpret_cast<int32_t*>(refine_lds + kFilterBits / 32);
+    float* s_val = reinterpret_cast<float*>(s_idx + q_cap);
+    const int qi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int64_t t0 = q_indptr[qi];
-    const int nt = min((int)(q_indptr[qi + 1] - t0), HR_MAX_QUERY_NNZ);
+    // a query longer than q_cap was already marked "never proven" by the prep kernel (q_eps = inf)
+    const int nt = min((int)(q_indptr[qi + 1] - t0), q_cap);
     for (int i = tid; i < kFilterBits / 32; i += 256) s_filter[i] = 0u;
     __syncthreads();
     for (int i = tid; i < nt; i += 256) {
@@ -350,42 +362,108 @@ __global__ __launch_bounds__(256) void refine_sparse_kernel(
         atomicOr(&s_filter[(t & (kFilterBits - 1)) >> 5], 1u << (t & 31));
     }
     __syncthreads();
-    const int slot = blockIdx.x * 256 + tid;  // candidate doc slot of this query
     const int n_slots = C * group_docs;
-    if (slot >= n_slots) return;
-    const int32_t group = cand[(int64_t)qi * C + slot / group_docs];
-    const int64_t o = (int64_t)qi * n_slots + slot;
-    const int64_t doc = (int64_t)group * group_docs + slot % group_docs;
-    bool valid = group >= 0 && doc < n_docs;
-    if (valid && rowmask) valid = (rowmask[doc >> 3] >> (doc & 7)) & 1;
-    float score = 0.f;
-    if (valid) {
-        double s = 0.0;
-        const int64_t e1 = indptr[doc + 1];
-        constexpr int U = 8;  // entries fetched per round trip
-        for (int64_t e = indptr[doc]; e < e1; e += U) {
-            int32_t t[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) t[u] = (e + u < e1) ? idx[e + u] : -1;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int32_t tt = t[u];
-                if (tt < 0) continue;
-                if (!((s_filter[(tt & (kFilterBits - 1)) >> 5] >> (tt & 31)) & 1u)) continue;
-                int lo = 0, hi = nt;  // first position with s_idx[pos] >= tt
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_idx[mid] < tt) lo = mid + 1; else hi = mid;
-                }
-                if (lo < nt && s_idx[lo] == tt)
-                    s = __dadd_rn(s, __dmul_rn((double)val[e + u], (double)s_val[lo]));
+    const int slot0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 256 + (tid & ~63));  // first doc slot of this wave
+    if (slot0 >= n_slots) return;
+    const int n_here = min(64, n_slots - slot0);
+    // lane l describes doc slot0 + l
+    const int slot = slot0 + lane;
+    int64_t doc = -1, p0 = 0;
+    int len = 0;
+    bool valid = false;
+    if (lane < n_here) {
+        const int32_t group = cand[(int64_t)qi * C + slot / group_docs];
+        doc = (int64_t)group * group_docs + slot % group_docs;
+        valid = group >= 0 && doc < n_docs;
+        if (valid && rowmask) valid = (rowmask[doc >> 3] >> (doc & 7)) & 1;
+        if (valid) {
+            p0 = indptr[doc];
+            len = (int)(indptr[doc + 1] - p0);
+        }
+    }
+    const unsigned int p0_lo = (unsigned int)p0, p0_hi = (unsigned int)((unsigned long long)p0 >> 32);
+    auto doc_start = [&](int j) -> int64_t {
+        return (int64_t)(((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)p0_hi, j) << 32) |
+                         (unsigned int)__builtin_amdgcn_readlane((int)p0_lo, j));
+    };
+    int32_t ri[kRefinePrefetch][2];
+    float rv[kRefinePrefetch][2];
+    auto fetch = [&](int j, int32_t (&ti)[2], float (&tv)[2]) {
+        ti[0] = ti[1] = -1;
+        tv[0] = tv[1] = 0.f;
+        if (j < n_here) {
+            const int n = __builtin_amdgcn_readlane(len, j);
+            const int64_t st = doc_start(j);
+            if (lane < n) {
+                ti[0] = idx[st + lane];
+                tv[0] = val[st + lane];
+            }
+            if (lane + 64 < n) {
+                ti[1] = idx[st + 64 + lane];
+                tv[1] = val[st + 64 + lane];
             }
         }
-        score = (float)s;
+    };
+    double s = 0.0;
+    auto consume = [&](int32_t tt, float vv) {  // one entry per lane; adds the matches in lane (= entry) order
+        bool hit = false;
+        double prod = 0.0;
+        if (tt >= 0 && ((s_filter[(tt & (kFilterBits - 1)) >> 5] >> (tt & 31)) & 1u)) {
+            int lo = 0, hi = nt;  // first position with s_idx[pos] >= tt
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (s_idx[mid] < tt) lo = mid + 1; else hi = mid;
+            }
+            if (lo < nt && s_idx[lo] == tt) {
+                hit = true;
+                prod = __dmul_rn((double)vv, (double)s_val[lo]);
+            }
+        }
+        unsigned long long m = __ballot(hit);
+        const unsigned long long pb = (unsigned long long)__double_as_longlong(prod);
+        const int pl = (int)(unsigned int)pb, ph = (int)(unsigned int)(pb >> 32);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const unsigned long long bits = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(ph, l) << 32) |
+                                            (unsigned int)__builtin_amdgcn_readlane(pl, l);
+            s = __dadd_rn(s, __longlong_as_double((long long)bits));
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < kRefinePrefetch; ++u) fetch(u, ri[u], rv[u]);
+    float my_score = 0.f;
+    for (int jb = 0; jb < n_here; jb += kRefinePrefetch) {
+#pragma unroll
+        for (int u = 0; u < kRefinePrefetch; ++u) {
+            const int j = jb + u;
+            const int32_t i0 = ri[u][0], i1 = ri[u][1];
+            const float v0 = rv[u][0], v1 = rv[u][1];
+            fetch(j + kRefinePrefetch, ri[u], rv[u]);
+            if (j < n_here) {
+                const int n = __builtin_amdgcn_readlane(len, j);
+                s = 0.0;
+                if (n > 0) {
+                    consume(i0, v0);
+                    if (n > 64) consume(i1, v1);
+                    if (n > 128) {  // long docs: the rest, not prefetched
+                        const int64_t st = doc_start(j);
+                        for (int off = 128; off < n; off += 64) {
+                            const bool in = off + lane < n;
+                            consume(in ? idx[st + off + lane] : -1, in ? val[st + off + lane] : 0.f);
+                        }
+                    }
+                }
+                if (lane == j) my_score = (float)s;
+            }
+        }
     }
-    const bool keep = valid && score > 0.f;
-    out_score[o] = keep ? score : -__builtin_inff();
-    out_row[o] = keep ? (int32_t)doc : -1;
+    if (lane < n_here) {
+        const int64_t o = (int64_t)qi * n_slots + slot;
+        const bool keep = valid && my_score > 0.f;
+        out_score[o] = keep ? my_score : -__builtin_inff();
+        out_row[o] = keep ? (int32_t)doc : -1;
+    }
 }
 
 }  // namespace hbmrag
