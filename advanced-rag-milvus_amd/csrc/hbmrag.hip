@@ -327,7 +327,8 @@ int launch_group_select(hr_index* h, Workspace* ws, hipStream_t s, int B, int64_
     const int64_t n_buckets = (n_groups + kBucketGroups - 1) / kBucketGroups;
     HIP_TRY(h, ws->bmax.ensure((size_t)B * n_buckets * sizeof(float)));
     if (n_groups > C && n_buckets > C) {
-        hipLaunchKernelGGL(bucket_max_kernel, dim3((unsigned)((n_buckets + 3) / 4), B), dim3(256), 0, s,
+        hipLaunchKernelGGL(bucket_max_kernel, dim3((unsigned)((n_buckets + 4 * kBucketsPerWave - 1) / (4 * kBucketsPerWave)), B),
+                           dim3(256), 0, s,
                            ws->gmax.as<float>(), n_groups, n_buckets, ws->bmax.as<float>());
         HIP_TRY(h, hipGetLastError());
     }

@@ -99,17 +99,30 @@ __device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, Select
     return prefix;
 }
 
-// Level-2 maxima: one wave per (query, bucket of 64 consecutive groups).
+// Level-2 maxima: a wave takes kBucketsPerWave consecutive buckets of 64 groups of one query and
+// issues all of their (coalesced, 256-byte) loads before the first reduction, so the pass streams the
+// table of group maxima instead of paying one round trip per bucket.
+constexpr int kBucketsPerWave = 8;
 __global__ __launch_bounds__(256) void bucket_max_kernel(const float* __restrict__ gmax, int64_t n_groups,
                                                          int64_t n_buckets, float* __restrict__ bmax) {
     const int q = blockIdx.y;
-    const int64_t bucket = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (bucket >= n_buckets) return;
     const int lane = threadIdx.x & 63;
-    const int64_t g = bucket * kBucketGroups + lane;
-    float v = g < n_groups ? gmax[(int64_t)q * n_groups + g] : -__builtin_inff();
-    v = wave_max(v);
-    if (lane == 0) bmax[(int64_t)q * n_buckets + bucket] = v;
+    const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kBucketsPerWave;
+    if (b0 >= n_buckets) return;
+    const float* gm = gmax + (int64_t)q * n_groups;
+    float v[kBucketsPerWave];
+#pragma unroll
+    for (int i = 0; i < kBucketsPerWave; ++i) {
+        const int64_t g = (b0 + i) * kBucketGroups + lane;
+        v[i] = g < n_groups ? gm[g] : -__builtin_inff();
+    }
+    float mine = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < kBucketsPerWave; ++i) {
+        const float m = wave_max(v[i]);
+        if (lane == i) mine = m;
+    }
+    if (lane < kBucketsPerWave && b0 + lane < n_buckets) bmax[(int64_t)q * n_buckets + b0 + lane] = mine;
 }
 
 // One block per query.  gmax[q][n_groups] (+ bmax[q][n_buckets]) -> cand[q][C]
