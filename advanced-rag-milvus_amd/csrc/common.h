@@ -50,6 +50,11 @@ __host__ __device__ inline int64_t chunk_index(int64_t row, int kchunk, int KT) 
     return (rb * KT + kt) * kTileChunks + rr + 16 * c;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + s_barrier and the
+// fence may drain every outstanding memory operation (s_waitcnt vmcnt(0)); a kernel that keeps
+// global loads in flight across the barrier wants to wait for its own LDS/scalar operations only.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ inline float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));

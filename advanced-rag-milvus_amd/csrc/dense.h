@@ -420,6 +420,182 @@ __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// 256-query scan, queries stationary in REGISTERS (fp16 shards with KT = 24 tiles per row, D = 768).
+//
+// dense_scan_bigq_kernel keeps the corpus in registers and re-streams the query tile from L2
+// through LDS every round; that extra traffic shares the CU's vector-memory path with the
+// corpus stream, and a 256-query form of it gains nothing.  Here the
+// roles are swapped:
+//   * wave w of the block owns 32 queries (GW = 2 groups of 16) and holds ALL their B fragments
+//     in registers (2 x 24 x 4 VGPRs) for the whole kernel: 8 waves = 256 queries per pass;
+//   * the block streams its corpus tiles HBM -> LDS with global_load_lds_dwordx4 (no VGPRs,
+//     one 1 KiB tile per wave instruction) into a ring of 64 tiles; every wave reads every tile
+//     once from LDS (ds_read_b128, conflict-free) and issues GW MFMAs per tile;
+//   * tiles move in stages of 8 (one tile per wave): per stage a wave waits for its own tile
+//     of that stage (counted s_waitcnt, 6 newer loads stay in flight), the block meets at an
+//     LDS-only barrier, the slot set everybody has just finished with is refilled, and the 8
+//     tiles are consumed.  Nothing but corpus bytes crosses the vector-memory path.
+// The 64 row scales of the NEXT super-group travel the same way (one 256-byte LDS-DMA load by wave 0,
+// a whole super-group ahead): an ordinary register load inside the loop would make the compiler wait
+// for it with vmcnt(0), i.e. drain the ring.  Epilogue and output (per-group maxima) as in the other scans.
+// Bound: LDS reads (8 waves x 1 KiB per tile = 8x the corpus rate; measured ~57 B/clk/CU of ds_read_b128),
+// i.e. 4.2 ms per 256 queries at 10M x 768 against 2 x 2.6 ms for two 128-query passes; with one group
+// per wave (128 queries) the same kernel is slower (3.4 ms) than dense_scan_bigq_kernel, so only GW = 2
+// is instantiated and batches up to 128 queries keep the other kernel.
+constexpr int kQregWaves = 8;         // 8 waves x 16 x GW queries per pass
+constexpr int kQregStageTiles = 8;    // tiles per stage = one per wave
+constexpr int kQregRingTiles = 64;    // 64 KiB of LDS, 7 stages (56 KiB) in flight per CU
+
+typedef __attribute__((address_space(1))) const void* hr_gptr_t;
+typedef __attribute__((address_space(3))) void* hr_lptr_t;
+
+template <int KT, int NRB, int GW>  // GW = 16-query groups per wave: 8 waves x 16 x GW queries per pass
+__global__ __launch_bounds__(64 * kQregWaves) void dense_scan_qreg_kernel(
+    const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
+    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int64_t n_rows, int64_t n_super) {
+    constexpr int NW = kQregWaves, T = kQregStageTiles, NS = kQregRingTiles / T;
+    constexpr int TPS = kRowBlocksPerSuper * KT;  // tiles of one 64-row super-group, contiguous in the shard
+    constexpr int H = T / 2;                      // tiles per half stage (LDS reads issued / awaited together)
+    static_assert(KT % T == 0 && NW == T && T == 8, "whole stages per row block, one tile per wave and stage");
+    static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
+    __shared__ chunk_t ring[kQregRingTiles * kTileChunks];
+    __shared__ f32x4_t sc_lds[2][kSuperRows / 4];  // row scales of the current / next super-group
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int quad = lane >> 4;
+    const float NEG_INF = -__builtin_inff();
+    const unsigned ring_lds = (unsigned)(uintptr_t)(hr_lptr_t)ring;        // LDS byte offsets for the asm reads
+    const unsigned sc_lds_addr = (unsigned)(uintptr_t)(hr_lptr_t)&sc_lds[0][0];
+    const int64_t first = blockIdx.x, step = gridDim.x;
+    if (first >= n_super) return;  // whole block
+    const int64_t n_my = (n_super - first + step - 1) / step;
+    const int64_t gmax_stride = n_super * (kRowBlocksPerSuper / NRB);
+
+    chunk_t qf[GW][KT];  // this wave's 16 * GW queries, every k-step
+#pragma unroll
+    for (int gq = 0; gq < GW; ++gq)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            qf[gq][kt] = qfrag[((int64_t)(wid * GW + gq) * KT + kt) * kTileChunks + lane];
+    // make the compiler settle these loads HERE (it waits before this "use"); otherwise it places an
+    // s_waitcnt vmcnt(0) in front of the first MFMA inside the loop, which would drain the ring every row block
+#pragma unroll
+    for (int gq = 0; gq < GW; ++gq)
+#pragma unroll
+        for (int kt = 0; kt < KT; kt += 8)
+            asm volatile("" : "+v"(qf[gq][kt]), "+v"(qf[gq][kt + 1]), "+v"(qf[gq][kt + 2]), "+v"(qf[gq][kt + 3]),
+                              "+v"(qf[gq][kt + 4]), "+v"(qf[gq][kt + 5]), "+v"(qf[gq][kt + 6]), "+v"(qf[gq][kt + 7]));
+
+    // loader: wave w brings tile w of every stage
+    int64_t ld_sg = first;
+    int ld_within = wid;
+    auto issue = [&](int stage_slot) {
+        const int64_t sg = ld_sg < n_super ? ld_sg : first;  // past the end: harmless re-read, keeps the count of loads in flight fixed
+        const chunk_t* src = tiles + (sg * TPS + ld_within) * kTileChunks + lane;
+        __builtin_amdgcn_global_load_lds((hr_gptr_t)src, (hr_lptr_t)(ring + (stage_slot * T + wid) * kTileChunks), 16, 0, 0);
+        ld_within += T;
+        if (ld_within >= TPS) {
+            ld_within -= TPS;
+            ld_sg += step;
+        }
+    };
+    auto issue_scale = [&](int64_t sg, int slot) {  // wave 0 only: one more (older) operation on its counter
+        const int64_t sgc = sg < n_super ? sg : first;
+        __builtin_amdgcn_global_load_lds((hr_gptr_t)(scale + sgc * kSuperRows + lane), (hr_lptr_t)&sc_lds[slot][0], 4, 0, 0);
+    };
+    if (wid == 0) issue_scale(first, 0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue(s);
+
+    int st = 0;  // stage slot of the stage about to be consumed
+    int64_t sg = first;
+    for (int64_t g = 0; g < n_my; ++g, sg += step) {
+        float m[GW];
+#pragma unroll
+        for (int gq = 0; gq < GW; ++gq) m[gq] = NEG_INF;
+        if (wid == 0) issue_scale(sg + step, (int)((g + 1) & 1));  // lands >= 7 stages before its first use
+        const bool tail = (sg + 1) * kSuperRows > n_rows || rowmask != nullptr;
+#pragma unroll 1
+        for (int rbi = 0; rbi < kRowBlocksPerSuper; ++rbi) {
+            f32x4_t acc[GW][2];
+#pragma unroll
+            for (int gq = 0; gq < GW; ++gq) acc[gq][0] = acc[gq][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ph = 0; ph < KT / T; ++ph) {
+                // own tile of this stage has landed: at least NS - 2 newer loads were issued after it
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 2) : "memory");
+                lds_barrier();
+                issue(st == 0 ? NS - 1 : st - 1);  // the slots of the stage everybody has just left
+                // LDS reads as inline asm: a ds_read the compiler can see after an LDS-DMA load makes it insert
+                // s_waitcnt vmcnt(0) ("may alias the DMA destination"), which would drain the ring every stage
+                const unsigned addr = ring_lds + (unsigned)(st * T * kTileChunks + lane) * 16u;
+                chunk_t a[H];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {  // GW = 2 leaves registers for four tiles at a time
+#pragma unroll
+                    for (int j = 0; j < H; ++j)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[j]) : "v"(addr), "n"((half * H + j) * 1024) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])::"memory");
+#pragma unroll
+                    for (int j = 0; j < H; ++j)
+#pragma unroll
+                        for (int gq = 0; gq < GW; ++gq)
+                            Mfma<_Float16>::run(a[j], qf[gq][ph * T + half * H + j], acc[gq][j & 1]);
+                }
+                st = (st + 1 == NS) ? 0 : st + 1;
+            }
+            // epilogue of the row block: lane holds rows quad*4..+3 of the block for query (lane & 15) of each group
+            float ok[4] = {1.f, 1.f, 1.f, 1.f};
+            const int64_t row0 = (sg * kRowBlocksPerSuper + rbi) * kRowsPerBlock + quad * 4;
+            f32x4_t sc;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(sc)
+                         : "v"(sc_lds_addr + (unsigned)(((g & 1) * (kSuperRows / 4) + rbi * (kRowsPerBlock / 4) + quad) * 16))
+                         : "memory");
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + r;
+                    bool v = row < n_rows;
+                    if (v && rowmask) v = (rowmask[row >> 3] >> (row & 7)) & 1;
+                    ok[r] = v ? 1.f : 0.f;
+                }
+            }
+#pragma unroll
+            for (int gq = 0; gq < GW; ++gq) {
+                const int q = 16 * (wid * GW + gq) + (lane & 15);
+                float mr = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = (acc[gq][0][r] + acc[gq][1][r]) * sc[r];
+                    v = (ok[r] != 0.f) ? v : NEG_INF;
+                    mr = fmaxf(mr, v);
+                }
+                if (NRB == 1) {
+                    mr = fmaxf(mr, __shfl_xor(mr, 16));
+                    mr = fmaxf(mr, __shfl_xor(mr, 32));
+                    if (lane < 16 && q < nq) gmax[(int64_t)q * gmax_stride + sg * kRowBlocksPerSuper + rbi] = mr;
+                } else {
+                    m[gq] = fmaxf(m[gq], mr);
+                }
+            }
+        }
+        if (NRB != 1) {
+#pragma unroll
+            for (int gq = 0; gq < GW; ++gq) {
+                const int q = 16 * (wid * GW + gq) + (lane & 15);
+                float v = m[gq];
+                v = fmaxf(v, __shfl_xor(v, 16));
+                v = fmaxf(v, __shfl_xor(v, 32));
+                if (lane < 16 && q < nq) gmax[(int64_t)q * gmax_stride + sg] = v;
+            }
+        }
+    }
+    // LDS DMA still in flight must land before the block's LDS is handed to another block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------
 // Canonical refine: 64 candidate rows per wave (group_rows = 16 or 64 rows per candidate group); lane = row.
 // score = (float) S with S the k-ordered fp64 sum of exact products.  The same
 // arithmetic is restated in oracle/oracle.c:dense_score().

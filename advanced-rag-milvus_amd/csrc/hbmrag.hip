@@ -316,6 +316,26 @@ hipError_t launch_scan_bigq_g(const hr_index* h, hipStream_t s, const chunk_t* q
                                               : launch_scan_bigq<STORE, 8, 4>(h, s, qfrag, mask, gmax, nq, n_super);
 }
 
+// 256-query pass with the queries in registers and the corpus streamed through LDS (dense_scan_qreg_kernel):
+// fp16 shards whose rows are 24 tiles long (D = 768 after padding; 2 x 24 x 4 fragment registers per wave).
+bool qreg_supported(const hr_index* h) {
+    static const bool off = std::getenv("HBMRAG_NO_QREG") != nullptr;
+    return !off && h->dtype == HR_F16 && h->KT == 24;
+}
+template <int KT, int NRB, int GW>
+hipError_t launch_scan_qreg(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                            int nq, int64_t n_super) {
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(n_super, (int64_t)h->cu_count));
+    hipLaunchKernelGGL((dense_scan_qreg_kernel<KT, NRB, GW>), dim3((unsigned)blocks), dim3(64 * kQregWaves), 0, s,
+                       h->tiles.as<chunk_t>(), qfrag, h->scale.as<float>(), mask, gmax, nq, h->n_rows, n_super);
+    return hipGetLastError();
+}
+hipError_t launch_scan_qreg_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                              int nq, int64_t n_super) {
+    return group_rows_for(h, h->n_rows) == 16 ? launch_scan_qreg<24, 1, 2>(h, s, qfrag, mask, gmax, nq, n_super)
+                                              : launch_scan_qreg<24, 4, 2>(h, s, qfrag, mask, gmax, nq, n_super);
+}
+
 int max_groups_for_dim(const hr_index* h) {
     // query tile must fit LDS: G * KT KiB <= 144 KiB
     int g = 156 / std::max(h->KT, 1);
@@ -380,7 +400,8 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     const int Gsmall = max_groups_for_dim(h);
     // batches beyond what fits LDS whole go through the k-chunked large-batch pass, 128 or 256 queries at a time
     const bool big = B > 16 * Gsmall && h->KT % 4 == 0 && std::getenv("HBMRAG_NO_BIGQ") == nullptr;
-    const int Gmax = big ? 8 : Gsmall;
+    const bool big256 = big && B > 128 && qreg_supported(h);   // 256 queries per pass, queries in registers
+    const int Gmax = big256 ? 16 : big ? 8 : Gsmall;
     const int chunk_q = 16 * Gmax;
     const size_t qfrag_bytes = (size_t)Gmax * h->KT * 1024;
     HIP_TRY(h, ws->qfrag.ensure(qfrag_bytes));
@@ -393,7 +414,8 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
 
     for (int c0 = 0; (phases & PHASE_SCAN) && c0 < B; c0 += chunk_q) {
         const int nq = std::min(chunk_q, B - c0);
-        const int G = big ? Gmax : (nq + 15) / 16;
+        const bool pass256 = big256 && nq > 128;   // a trailing chunk of <= 128 queries takes the 128-query pass
+        const int G = big ? (pass256 ? 16 : 8) : (nq + 15) / 16;
         {
             Span sp(h, s, PH_PREP);
             if (h->dtype == HR_F16)
@@ -410,7 +432,9 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
             Span sp(h, s, PH_SCAN);
             float* gm = ws->gmax.as<float>() + (int64_t)c0 * n_groups;
             hipError_t e;
-            if (big)
+            if (pass256)
+                e = launch_scan_qreg_g(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+            else if (big)
                 e = (h->dtype == HR_F16)
                         ? launch_scan_bigq_g<_Float16>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
                         : launch_scan_bigq_g<float>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);

@@ -9,16 +9,21 @@ import oracle
 # parity first (small corpus, B=200 -> GQ=16; B=100 -> GQ=8)
 rng = np.random.default_rng(0)
 for dt, npdt in (() if os.environ.get('SKIP_PARITY') else ((nat.HR_F16, np.float16), (nat.HR_F32, np.float32))):
-    for n in (5000, 70000):
-        X = rng.standard_normal((n, 256)).astype(np.float32).astype(npdt)
-        h = nat.ShardHandle(256, dt, nat.HR_METRIC_COSINE); h.add_dense(X); h.finalize()
-        for B in (100, 200, 300):
-            Q = rng.standard_normal((B, 256)).astype(np.float32)
-            ids, sc = h.search_dense(Q, 40)
-            oids, osc = oracle.dense_search(X[:, :], Q[:8], 40, oracle.COSINE)
-            oids2, osc2 = oracle.dense_search(X, Q[-4:], 40, oracle.COSINE)
-            ok = np.array_equal(ids[:8], oids) and np.array_equal(sc[:8].view(np.uint32), osc.view(np.uint32)) and np.array_equal(ids[-4:], oids2)
-            print("parity", "f16" if dt == nat.HR_F16 else "f32", n, B, ok, flush=True)
+    for n, D in ((5000, 256), (70000, 256), (3333, 768), (70001, 768), (40000, 1024), (250000, 768)):
+        X = rng.standard_normal((n, D)).astype(np.float32).astype(npdt)
+        X[n // 2] = X[7]  # a tie
+        h = nat.ShardHandle(D, dt, nat.HR_METRIC_COSINE); h.add_dense(X); h.finalize()
+        mask = np.packbits(rng.random(n) < 0.7, bitorder="little")
+        for B in (100, 128, 200, 300):
+            Q = rng.standard_normal((B, D)).astype(np.float32)
+            Q[1] = X[7].astype(np.float32)
+            ok = True
+            for m in (None, mask):
+                ids, sc = h.search_dense(Q, 40, m)
+                sel = [0, 1, 2, B // 2, B - 2, B - 1]
+                oids, osc = oracle.dense_search(X, Q[sel], 40, oracle.COSINE, mask=m)
+                ok = ok and np.array_equal(ids[sel], oids) and np.array_equal(sc[sel].view(np.uint32), osc.view(np.uint32))
+            print("parity", "f16" if dt == nat.HR_F16 else "f32", n, D, B, ok, flush=True)
         h.close()
 
 N, D = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 768

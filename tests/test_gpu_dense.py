@@ -174,3 +174,29 @@ def test_large_batches_take_the_chunked_query_pass(gpu, dtype, np_dtype, n, d, B
     oids, osc = oracle.dense_search(X, Q[pick], 40, nat.HR_METRIC_COSINE, mask)
     assert np.array_equal(ids[pick], oids) and np.array_equal(_bits(sc[pick]), _bits(osc))
     h.close()
+
+
+@pytest.mark.parametrize("metric", [nat.HR_METRIC_COSINE, nat.HR_METRIC_IP])
+@pytest.mark.parametrize("n,B", [(3333, 129), (70001, 256), (70001, 300), (250000, 200), (63, 130)])
+def test_256_query_pass_queries_in_registers(gpu, metric, n, B):
+    """128 < B at D = 768 fp16: the 256-query pass (queries in registers, corpus streamed HBM -> LDS by DMA) must give
+    the oracle's lists at every query position, with a row mask, a duplicated row, a ragged tail group and the ragged
+    last pass (B = 300 -> 256 + 44 through the 128-query pass)."""
+    rng = np.random.default_rng(n + B)
+    d = 768
+    X = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    X[n // 2] = X[7]
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[1] = X[7].astype(np.float32)
+    h = nat.ShardHandle(d, nat.HR_F16, metric)
+    h.add_dense(X[: n // 3])
+    h.add_dense(X[n // 3:])
+    h.finalize()
+    pick = sorted(set([0, 1, 15, 16, 31, 32, 127, 128, 129, 255, 256, B - 1, B // 2]) & set(range(B)))
+    k = min(40, n)
+    for m in (None, np.packbits(rng.random(n) < 0.6, bitorder="little")):
+        ids, sc = h.search_dense(Q, k, m)
+        oids, osc = oracle.dense_search(X, Q[pick], k, metric, m)
+        assert np.array_equal(ids[pick], oids)
+        assert np.array_equal(_bits(sc[pick]), _bits(osc))
+    h.close()
