@@ -438,27 +438,30 @@ __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
 // The 64 row scales of the NEXT super-group travel the same way (one 256-byte LDS-DMA load by wave 0,
 // a whole super-group ahead): an ordinary register load inside the loop would make the compiler wait
 // for it with vmcnt(0), i.e. drain the ring.  Epilogue and output (per-group maxima) as in the other scans.
-// Bound: LDS reads (8 waves x 1 KiB per tile = 8x the corpus rate; measured ~57 B/clk/CU of ds_read_b128),
-// i.e. 4.2 ms per 256 queries at 10M x 768 against 2 x 2.6 ms for two 128-query passes; with one group
-// per wave (128 queries) the same kernel is slower (3.4 ms) than dense_scan_bigq_kernel, so only GW = 2
-// is instantiated and batches up to 128 queries keep the other kernel.
-constexpr int kQregWaves = 8;         // 8 waves x 16 x GW queries per pass
-constexpr int kQregStageTiles = 8;    // tiles per stage = one per wave
-constexpr int kQregRingTiles = 64;    // 64 KiB of LDS, 7 stages (56 KiB) in flight per CU
+// Measured at 10M x 768: 4.0 ms per 256 queries (3.85 TB/s) against 2 x 2.6 ms for two 128-query passes.
+// The DMA stream alone (no LDS reads, no MFMAs) runs at 5.06 TB/s with nontemporal loads (4.3 TB/s without the
+// hint; a ring of 64 instead of 128 tiles changes nothing), and the 2 x 8 MFMAs + 8 LDS reads per wave and stage
+// add ~1 ms that the per-stage barrier keeps from overlapping fully.  A 128-query form (4 waves x 32 queries, two
+// blocks per CU) measures 2.63 ms alone and the same step time as dense_scan_bigq_kernel inside the pipeline, so
+// batches up to 128 queries keep that kernel (any D, fp32 too) and only the 8-wave form is instantiated.
+constexpr int kQregStageTiles = 8;    // tiles per stage (one or two per wave)
+constexpr int kQregRingTiles = 128;   // 128 KiB of LDS, 15 stages (120 KiB) in flight per block
 
 typedef __attribute__((address_space(1))) const void* hr_gptr_t;
 typedef __attribute__((address_space(3))) void* hr_lptr_t;
 
-template <int KT, int NRB, int GW>  // GW = 16-query groups per wave: 8 waves x 16 x GW queries per pass
-__global__ __launch_bounds__(64 * kQregWaves) void dense_scan_qreg_kernel(
+template <int KT, int NRB, int GW, int NW>  // NW waves x GW groups of 16 queries per pass
+__global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
     const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
     const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int64_t n_rows, int64_t n_super) {
-    constexpr int NW = kQregWaves, T = kQregStageTiles, NS = kQregRingTiles / T;
+    constexpr int kRing = kQregRingTiles * NW / 8;  // 128 KiB for one 8-wave block per CU, 64 KiB each for two 4-wave blocks
+    constexpr int T = kQregStageTiles, NS = kRing / T;
+    constexpr int L = T / NW;                     // tiles a wave loads per stage
     constexpr int TPS = kRowBlocksPerSuper * KT;  // tiles of one 64-row super-group, contiguous in the shard
     constexpr int H = T / 2;                      // tiles per half stage (LDS reads issued / awaited together)
-    static_assert(KT % T == 0 && NW == T && T == 8, "whole stages per row block, one tile per wave and stage");
+    static_assert(KT % T == 0 && T % NW == 0 && T == 8, "whole stages per row block, the same number of tiles per wave and stage");
     static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
-    __shared__ chunk_t ring[kQregRingTiles * kTileChunks];
+    __shared__ chunk_t ring[kRing * kTileChunks];
     __shared__ f32x4_t sc_lds[2][kSuperRows / 4];  // row scales of the current / next super-group
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -492,7 +495,10 @@ __global__ __launch_bounds__(64 * kQregWaves) void dense_scan_qreg_kernel(
     auto issue = [&](int stage_slot) {
         const int64_t sg = ld_sg < n_super ? ld_sg : first;  // past the end: harmless re-read, keeps the count of loads in flight fixed
         const chunk_t* src = tiles + (sg * TPS + ld_within) * kTileChunks + lane;
-        __builtin_amdgcn_global_load_lds((hr_gptr_t)src, (hr_lptr_t)(ring + (stage_slot * T + wid) * kTileChunks), 16, 0, 0);
+#pragma unroll
+        for (int l = 0; l < L; ++l)  // tiles wid, wid + NW, ... of the stage (all inside the same super-group)
+            __builtin_amdgcn_global_load_lds((hr_gptr_t)(src + l * NW * kTileChunks),
+                                             (hr_lptr_t)(ring + (stage_slot * T + wid + l * NW) * kTileChunks), 16, 0, 2 /* nt: each byte is read once */);
         ld_within += T;
         if (ld_within >= TPS) {
             ld_within -= TPS;
@@ -522,8 +528,8 @@ __global__ __launch_bounds__(64 * kQregWaves) void dense_scan_qreg_kernel(
             for (int gq = 0; gq < GW; ++gq) acc[gq][0] = acc[gq][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ph = 0; ph < KT / T; ++ph) {
-                // own tile of this stage has landed: at least NS - 2 newer loads were issued after it
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NS - 2) : "memory");
+                // own tiles of this stage have landed: at least (NS - 2) * L newer loads were issued after them
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * L) : "memory");
                 lds_barrier();
                 issue(st == 0 ? NS - 1 : st - 1);  // the slots of the stage everybody has just left
                 // LDS reads as inline asm: a ds_read the compiler can see after an LDS-DMA load makes it insert

@@ -322,20 +322,20 @@ bool qreg_supported(const hr_index* h) {
     static const bool off = std::getenv("HBMRAG_NO_QREG") != nullptr;
     return !off && h->dtype == HR_F16 && h->KT == 24;
 }
-template <int KT, int NRB, int GW>
+template <int KT, int NRB, int GW, int NW>
 hipError_t launch_scan_qreg(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
                             int nq, int64_t n_super) {
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(n_super, (int64_t)h->cu_count));
-    hipLaunchKernelGGL((dense_scan_qreg_kernel<KT, NRB, GW>), dim3((unsigned)blocks), dim3(64 * kQregWaves), 0, s,
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(n_super, (int64_t)h->cu_count * (8 / NW)));
+    hipLaunchKernelGGL((dense_scan_qreg_kernel<KT, NRB, GW, NW>), dim3((unsigned)blocks), dim3(64 * NW), 0, s,
                        h->tiles.as<chunk_t>(), qfrag, h->scale.as<float>(), mask, gmax, nq, h->n_rows, n_super);
     return hipGetLastError();
 }
+// 256 queries per pass: 8 waves x 32 queries, one block per CU
 hipError_t launch_scan_qreg_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
                               int nq, int64_t n_super) {
-    return group_rows_for(h, h->n_rows) == 16 ? launch_scan_qreg<24, 1, 2>(h, s, qfrag, mask, gmax, nq, n_super)
-                                              : launch_scan_qreg<24, 4, 2>(h, s, qfrag, mask, gmax, nq, n_super);
+    return group_rows_for(h, h->n_rows) == 16 ? launch_scan_qreg<24, 1, 2, 8>(h, s, qfrag, mask, gmax, nq, n_super)
+                                              : launch_scan_qreg<24, 4, 2, 8>(h, s, qfrag, mask, gmax, nq, n_super);
 }
-
 int max_groups_for_dim(const hr_index* h) {
     // query tile must fit LDS: G * KT KiB <= 144 KiB
     int g = 156 / std::max(h->KT, 1);

@@ -77,6 +77,16 @@ def pmc_traffic(rows: int, dim: int, batch: int, n_gpus: int):
     return None, None
 
 
+def scan_kernel_name(B: int, dim: int) -> str:
+    """Which dense scan serves a batch of B queries (dense_search_enqueue in csrc/hbmrag.hip)."""
+    kt = -(-(-(-dim // 32)) // 4) * 4          # 1 KiB tiles per row, padded to a multiple of 4
+    if B > 128 and kt == 24:
+        return "dense_scan_qreg_kernel<KT=24,GW=2,NW=8> (256 queries per pass)"
+    if B > 64:
+        return "dense_scan_bigq_kernel<f16,GQ=8> (128 queries per pass)"
+    return "dense_scan_kernel<f16> (up to 64 queries per pass)"
+
+
 def make_queries(n_batches: int, B: int, dim: int, seed: int = 4321):
     rng = np.random.default_rng(seed)
     Q = rng.standard_normal((n_batches, B, dim), dtype=np.float32)
@@ -351,7 +361,7 @@ def main():
                        "rows": N, "dim": D, "batch": B, "top_k": args.top_k, "k_prime": kp,
                        "batches_in_flight": n_fly,
                        "parallelism": f"row-sharded x{world}, one RCCL all-gather of per-shard top-k' per step" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "dense_scan_bigq_kernel<f16,GQ=8>" if B > 64 else "dense_scan_kernel<f16>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": scan_kernel_name(B, D), "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches},
