@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel phase, not just the scans")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="query batches kept in flight: 1 = one batch at a time; 2..4 = scans of batch i+1 on a heavy "
                          "stream while batch i is finished (select/refine/exchange/fuse) on a light stream")
     args = ap.parse_args()
