@@ -309,6 +309,16 @@ def main():
         dist.all_reduce(ft, op=dist.ReduceOp.MIN)
         flags_exact = bool(ft.item())
 
+    # every rank merges the same gathered lists, so every rank must hold the same fused answer for the last batch
+    ranks_agree = None
+    if world > 1:
+        w8 = torch.arange(1, out["fused_ids"].numel() + 1, dtype=torch.int64, device=out["fused_ids"].device)
+        chk = (out["fused_ids"].reshape(-1).to(torch.int64) * w8).sum().reshape(1)
+        chk = chk.cpu() if rehearsal else chk
+        allc = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        ranks_agree = all(int(c.item()) == int(allc[0].item()) for c in allc)
+
     scan_ms, scan_launches = phases["dense_scan"]
     scan_bytes = h.dense_scan_bytes
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
@@ -367,7 +377,7 @@ def main():
                          "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches},
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
-            "all_lists_proven_exact": flags_exact,
+            "all_lists_proven_exact": flags_exact, **({"ranks_agree": ranks_agree} if ranks_agree is not None else {}),
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
         }
         if latency:
