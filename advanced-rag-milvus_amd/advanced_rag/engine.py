@@ -280,8 +280,14 @@ class PipelinedSearchEngine(HybridSearchEngine):
             raise ValueError("depth must be 1..4 (HR_MAX_SLOTS)")
         t = self.torch
         self.depth = depth
+        # The light stream is created with HIGH priority.  HIP multiplexes streams onto a few hardware queues
+        # (round-robin in creation order), and two streams that land on the same queue execute in enqueue order:
+        # batch i's finish work would then sit between scan(i) and scan(i+1) instead of beside scan(i+1)
+        # (seen as 4.8-4.95 ms/step instead of 4.45-4.65 whenever other streams had been created first, e.g. by the
+        # host-form searches of bench.py's parity gate).  Queues are per priority level, so a high-priority light
+        # stream can never share one with the normal-priority heavy stream.
         self.heavy = t.cuda.Stream(self.device)
-        self.light = t.cuda.Stream(self.device)
+        self.light = t.cuda.Stream(self.device, priority=-1)
         self._slot_bufs = [dict() for _ in range(depth)]
         self._n = 0
         # optional callable(buffers) run on the light stream after fusion/rerank of every batch, before the
