@@ -117,6 +117,32 @@ def test_fullsize_dense_properties(shards):
     assert np.array_equal(mi.cpu().numpy(), ids) and np.array_equal(ms.cpu().numpy().view(np.uint32), sc.view(np.uint32))
 
 
+def test_fullsize_batch_kernels_agree(shards):
+    """The three dense scans (<= 64 queries: queries in LDS; <= 128: query tile streamed through LDS; <= 256: queries in
+    registers, corpus through LDS by DMA) are different candidate generators in front of the same canonical refine:
+    at 10M rows they must return identical lists, and every list must be proven exact."""
+    whole, _ = shards
+    rng = np.random.default_rng(77)
+    Q = rng.standard_normal((256, D)).astype(np.float32)
+    Q[200] = _rows([5]).astype(np.float32)[0]            # row 5 has an exact duplicate at 3*BLK+17
+    i256, s256 = whole.search_dense(Q, K)
+    assert i256[200, 0] == 5 and i256[200, 1] == 3 * BLK + 17
+    i128, s128 = whole.search_dense(Q[:128], K)
+    assert np.array_equal(i128, i256[:128]) and np.array_equal(s128.view(np.uint32), s256[:128].view(np.uint32))
+    for j0 in (0, 192):
+        i64, s64 = whole.search_dense(Q[j0:j0 + 64], K)
+        assert np.array_equal(i64, i256[j0:j0 + 64])
+        assert np.array_equal(s64.view(np.uint32), s256[j0:j0 + 64].view(np.uint32))
+    dq = torch.from_numpy(Q).cuda()
+    di = torch.empty((256, K), dtype=torch.int64, device="cuda")
+    ds = torch.empty((256, K), dtype=torch.float32, device="cuda")
+    fl = torch.zeros((256,), dtype=torch.int32, device="cuda")
+    whole.search_dense_dev(dq.data_ptr(), 256, K, di.data_ptr(), ds.data_ptr(), fl.data_ptr(), 0,
+                           torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(fl.min()) == 1 and np.array_equal(di.cpu().numpy(), i256)
+
+
 def test_fullsize_rowmask_monotone(shards):
     """Restricting the corpus can only remove results: masked lists are the unmasked ranking filtered."""
     whole, _ = shards
