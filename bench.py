@@ -148,7 +148,13 @@ def main():
         if rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            # RCCL's internal stream at high priority: HIP maps streams to hardware queues per priority level, so
+            # the all-gather can never queue up behind a scan of the (normal-priority) heavy stream
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=dev)
 
     def log(msg):
         if rank == 0:
