@@ -153,7 +153,9 @@ def main():
             try:
                 opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
                 dist.init_process_group("nccl", device_id=dev, pg_options=opts)
-            except (AttributeError, TypeError):
+            except Exception:  # older torch without the option: plain group
+                if dist.is_initialized():
+                    raise
                 dist.init_process_group("nccl", device_id=dev)
 
     def log(msg):
