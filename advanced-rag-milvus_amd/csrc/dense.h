@@ -431,21 +431,21 @@ __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
 //   * the block streams its corpus tiles HBM -> LDS with global_load_lds_dwordx4 (no VGPRs,
 //     one 1 KiB tile per wave instruction) into a ring of 64 tiles; every wave reads every tile
 //     once from LDS (ds_read_b128, conflict-free) and issues GW MFMAs per tile;
-//   * tiles move in stages of 8 (one tile per wave): per stage a wave waits for its own tile
-//     of that stage (counted s_waitcnt, 6 newer loads stay in flight), the block meets at an
-//     LDS-only barrier, the slot set everybody has just finished with is refilled, and the 8
-//     tiles are consumed.  Nothing but corpus bytes crosses the vector-memory path.
+//   * tiles move in stages of one row block (KT = 24 tiles, three per wave): per stage a wave waits for
+//     its own tiles of that stage (counted s_waitcnt, the loads of three newer stages stay in flight),
+//     the block meets at an LDS-only barrier, the slot set everybody has just finished with is
+//     refilled, and the 24 tiles are consumed four at a time.  Nothing but corpus bytes crosses the
+//     vector-memory path.
 // The 64 row scales of the NEXT super-group travel the same way (one 256-byte LDS-DMA load by wave 0,
 // a whole super-group ahead): an ordinary register load inside the loop would make the compiler wait
 // for it with vmcnt(0), i.e. drain the ring.  Epilogue and output (per-group maxima) as in the other scans.
-// Measured at 10M x 768: 4.0 ms per 256 queries (3.85 TB/s) against 2 x 2.6 ms for two 128-query passes.
-// The DMA stream alone (no LDS reads, no MFMAs) runs at 5.06 TB/s with nontemporal loads (4.3 TB/s without the
-// hint; a ring of 64 instead of 128 tiles changes nothing), and the 2 x 8 MFMAs + 8 LDS reads per wave and stage
-// add ~1 ms that the per-stage barrier keeps from overlapping fully.  A 128-query form (4 waves x 32 queries, two
+// Measured at 10M x 768: 3.8 ms per 256 queries (4.04 TB/s) against 2 x 2.6 ms for two 128-query passes (stages of
+// 8 tiles, i.e. three barriers per row block: 4.0 ms).  The DMA stream alone (no LDS reads, no MFMAs) runs at
+// 5.06 TB/s with nontemporal loads (4.3 TB/s without the hint; ring depth changes nothing), and the LDS reads
+// (8 waves x 1 KiB per tile, ~50 B/clk/CU) are what the rest of the time goes to.  A 128-query form (4 waves x 32 queries, two
 // blocks per CU) measures 2.63 ms alone and the same step time as dense_scan_bigq_kernel inside the pipeline, so
 // batches up to 128 queries keep that kernel (any D, fp32 too) and only the 8-wave form is instantiated.
-constexpr int kQregStageTiles = 8;    // tiles per stage (one or two per wave)
-constexpr int kQregRingTiles = 128;   // 128 KiB of LDS, 15 stages (120 KiB) in flight per block
+constexpr int kQregStages = 5;        // ring depth in stages of one row block (KT tiles): 5 x 24 KiB of LDS, 4 stages in flight
 
 typedef __attribute__((address_space(1))) const void* hr_gptr_t;
 typedef __attribute__((address_space(3))) void* hr_lptr_t;
@@ -454,12 +454,12 @@ template <int KT, int NRB, int GW, int NW>  // NW waves x GW groups of 16 querie
 __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
     const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
     const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int64_t n_rows, int64_t n_super) {
-    constexpr int kRing = kQregRingTiles * NW / 8;  // 128 KiB for one 8-wave block per CU, 64 KiB each for two 4-wave blocks
-    constexpr int T = kQregStageTiles, NS = kRing / T;
+    constexpr int T = KT, NS = kQregStages;       // one stage = the KT tiles of one row block (one barrier per row block)
+    constexpr int kRing = NS * T;
     constexpr int L = T / NW;                     // tiles a wave loads per stage
     constexpr int TPS = kRowBlocksPerSuper * KT;  // tiles of one 64-row super-group, contiguous in the shard
-    constexpr int H = T / 2;                      // tiles per half stage (LDS reads issued / awaited together)
-    static_assert(KT % T == 0 && T % NW == 0 && T == 8, "whole stages per row block, the same number of tiles per wave and stage");
+    constexpr int H = 4;                          // tiles whose LDS reads are issued / awaited together
+    static_assert(KT % T == 0 && T % NW == 0 && T % H == 0, "whole stages per row block, the same number of tiles per wave and stage");
     static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
     __shared__ chunk_t ring[kRing * kTileChunks];
     __shared__ f32x4_t sc_lds[2][kSuperRows / 4];  // row scales of the current / next super-group
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
                 const unsigned addr = ring_lds + (unsigned)(st * T * kTileChunks + lane) * 16u;
                 chunk_t a[H];
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {  // GW = 2 leaves registers for four tiles at a time
+                for (int half = 0; half < T / H; ++half) {  // GW = 2 leaves registers for four tiles at a time
 #pragma unroll
                     for (int j = 0; j < H; ++j)
                         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[j]) : "v"(addr), "n"((half * H + j) * 1024) : "memory");
