@@ -123,14 +123,18 @@ class EngineConfig:
     method_bonus: float = 0.1
     recency_weight: float = 0.0
     use_sparse: bool = True
+    domain_weight: float = 0.2    # weight of the optional domain list (reference retrieval.py:455-468)
 
 
 class HybridSearchEngine:
     def __init__(self, handle: "nat.ShardHandle", config: Optional[EngineConfig] = None, process_group=None,
-                 device: Optional[str] = None, stream=None):
+                 device: Optional[str] = None, stream=None, domain_handle: "Optional[nat.ShardHandle]" = None):
         import torch
         self.torch = torch
         self.h = handle
+        # optional third modality (reference _search_domain, retrieval.py:397-419): a second dense shard over the same
+        # rows searched with k = top_k (not 2k) and fused with weight 0.2; single-shard engines only
+        self.hd = domain_handle
         self.cfg = config or EngineConfig()
         self.group = process_group
         self.dist = None
@@ -170,6 +174,10 @@ class HybridSearchEngine:
             "rr_scores": t.empty((B, cfg.rerank_top_k), dtype=t.float64, device=dev),
             "rr_orig": t.empty((B, cfg.rerank_top_k), dtype=t.float64, device=dev),
         }
+        if self.hd is not None:
+            b["dom_ids"] = t.empty((B, cfg.top_k), dtype=t.int64, device=dev)
+            b["dom_scores"] = t.empty((B, cfg.top_k), dtype=t.float32, device=dev)
+            b["dom_flags"] = t.zeros((B,), dtype=t.int32, device=dev)
         if self.world > 1:
             b["gathered"] = t.empty((self.world, layout.nbytes), dtype=t.uint8, device=dev)
             b["m_ids"] = t.empty((n_mod, B, kp), dtype=t.int64, device=dev)
@@ -178,13 +186,16 @@ class HybridSearchEngine:
         return b
 
     # ------------------------------------------------------------------ one batch
-    def search(self, q, sparse=None) -> dict:
+    def search(self, q, sparse=None, domain_q=None) -> dict:
         """q: float32 [B, dim] device tensor.  sparse: (indptr int64[B+1], idx int32, val float32, max_nnz)
-        device tensors from `upload_sparse`.  Asynchronous on the current stream; returns the
+        device tensors from `upload_sparse`.  domain_q: float32 [B, domain_dim] device tensor for the optional
+        domain shard (engine built with domain_handle).  Asynchronous on the current stream; returns the
         buffer dict (fused_* and rr_* tensors are the results; they are reused by the next call)."""
         if self.stream is not None and self.torch.cuda.current_stream(self.device) != self.stream:
             with self.torch.cuda.stream(self.stream):
-                return self.search(q, sparse)
+                return self.search(q, sparse, domain_q)
+        if domain_q is not None and (self.hd is None or self.world > 1):
+            raise ValueError("domain queries need an engine built with domain_handle on a single shard")
         t, cfg = self.torch, self.cfg
         B = q.shape[0]
         b = self._buffers(B)
@@ -199,6 +210,10 @@ class HybridSearchEngine:
         else:
             self.h.search_dense_dev(q.data_ptr(), B, kp, b["ids"][0].data_ptr(), b["scores"][0].data_ptr(),
                                     b["flags"][0].data_ptr(), 0, stream)
+        b["use_domain"] = domain_q is not None
+        if domain_q is not None:
+            self.hd.search_dense_dev(domain_q.data_ptr(), B, cfg.top_k, b["dom_ids"].data_ptr(),
+                                     b["dom_scores"].data_ptr(), b["dom_flags"].data_ptr(), 0, stream)
         return self._post_lists(b, B, stream)
 
     def _post_lists(self, b: dict, B: int, stream: int) -> dict:
@@ -213,8 +228,10 @@ class HybridSearchEngine:
                                    b["m_ids"][m].data_ptr(), b["m_scores"][m].data_ptr(), stream,
                                    score_stride=sc_stride, id_stride=id_stride)
             ids, scores = b["m_ids"], b["m_scores"]
+        dom = b.get("use_domain", False)
         nat.fuse_rrf_dev(ids[0].data_ptr(), kp, ids[1].data_ptr() if cfg.use_sparse else 0,
-                         kp if cfg.use_sparse else 0, 0, 0, B, cfg.dense_weight, cfg.sparse_weight, 0.2, cfg.rrf_k,
+                         kp if cfg.use_sparse else 0, b["dom_ids"].data_ptr() if dom else 0, cfg.top_k if dom else 0, B,
+                         cfg.dense_weight, cfg.sparse_weight, cfg.domain_weight, cfg.rrf_k,
                          cfg.top_k, b["fused_ids"].data_ptr(), b["fused_scores"].data_ptr(),
                          b["fused_methods"].data_ptr(), b["fused_n"].data_ptr(), stream)
         if cfg.enable_reranking:

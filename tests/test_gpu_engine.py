@@ -355,3 +355,52 @@ def test_config3_1m_768_hybrid_matches_oracle(gpu):
         assert np.array_equal(out["fused_scores"][b].cpu().numpy().view(np.uint64), fs.view(np.uint64))
         assert np.array_equal(out["rr_ids"][b].cpu().numpy(), reranked[j][0])
     h.close()
+
+
+def test_engine_with_domain_list_matches_oracle(gpu):
+    """Third modality in the batched engine (reference _search_domain, retrieval.py:397-419): a second dense shard over
+    the same rows, k = top_k (not 2k), fused with weight 0.2 after the semantic and sparse lists."""
+    n, d, dd, V, nnz, B, top_k = 5000, 128, 96, 600, 10, 11, 20
+    X, ptr, idx, val, Q, SQ = corpus(n, d, V, nnz, B, seed=5)
+    rng = np.random.default_rng(6)
+    Xd = rng.standard_normal((n, dd)).astype(np.float32).astype(np.float16)
+    Qd = rng.standard_normal((B, dd)).astype(np.float32)
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    h.add_dense(X)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    hd = nat.ShardHandle(dd, nat.HR_F16, nat.HR_METRIC_COSINE)
+    hd.add_dense(Xd)
+    hd.finalize()
+    cfg = EngineConfig(top_k=top_k)
+    eng = HybridSearchEngine(h, cfg, domain_handle=hd)
+    out = eng.search(torch.from_numpy(Q).cuda(), eng.upload_sparse(pack_sparse_queries(SQ, 0.2)), torch.from_numpy(Qd).cuda())
+    torch.cuda.synchronize()
+    kp = 2 * top_k
+    di, _ = oracle.dense_search(X, Q, kp, oracle.COSINE)
+    si, _ = oracle.sparse_search(ptr, idx, val, SQ, kp, 0.2)
+    ci, cs = oracle.dense_search(Xd, Qd, top_k, oracle.COSINE)
+    assert np.array_equal(out["dom_ids"].cpu().numpy(), ci)
+    assert np.array_equal(out["dom_scores"].cpu().numpy().view(np.uint32), cs.view(np.uint32))
+    assert out["dom_flags"].min().item() == 1
+    saw_domain_only = False
+    for b in range(B):
+        fi, fs, fm = oracle.rrf(di[b], si[b][si[b] >= 0], ci[b], cfg.dense_weight, cfg.sparse_weight, 0.2, cfg.rrf_k)
+        fi, fs, fm = fi[:top_k], fs[:top_k], fm[:top_k]
+        nf = int(out["fused_n"][b])
+        assert nf == len(fi)
+        assert np.array_equal(out["fused_ids"][b, :nf].cpu().numpy(), fi)
+        assert np.array_equal(out["fused_scores"][b, :nf].cpu().numpy().view(np.uint64), fs.view(np.uint64))
+        assert np.array_equal(out["fused_methods"][b, :nf].cpu().numpy(), fm)
+        saw_domain_only |= bool((fm & 4).any())
+    assert saw_domain_only
+    # without domain queries the same engine gives the two-list answer again
+    out = eng.search(torch.from_numpy(Q).cuda(), eng.upload_sparse(pack_sparse_queries(SQ, 0.2)))
+    torch.cuda.synchronize()
+    fi, fs, fm = oracle.rrf(di[0], si[0][si[0] >= 0], (), cfg.dense_weight, cfg.sparse_weight, 0.2, cfg.rrf_k)
+    assert np.array_equal(out["fused_ids"][0, :top_k].cpu().numpy(), fi[:top_k])
+    with pytest.raises(ValueError):
+        HybridSearchEngine(h, cfg).search(torch.from_numpy(Q).cuda(), eng.upload_sparse(pack_sparse_queries(SQ, 0.2)),
+                                          torch.from_numpy(Qd).cuda())
+    h.close()
+    hd.close()
