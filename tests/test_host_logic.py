@@ -400,3 +400,42 @@ def test_bm25_encoder_scores_equal_textbook_bm25():
     want = sum(idf(2) * tf * 2.2 / (tf + 1.2 * (1 - 0.75 + 0.75 * 3 / avgdl)) for tf in (2, 1))
     assert abs(scores[2] - want) < 1e-5
     assert q["indices"] == sorted(q["indices"])
+
+
+def test_bench_names_the_dense_scan_kernel_per_batch():
+    """bench.py's roofline.kernel label follows the dispatch in csrc/hbmrag.hip::dense_search_enqueue."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert "dense_scan_kernel" in mod.scan_kernel_name(1, 768) and "dense_scan_kernel" in mod.scan_kernel_name(64, 768)
+    assert "bigq" in mod.scan_kernel_name(65, 768) and "bigq" in mod.scan_kernel_name(128, 768)
+    assert "qreg" in mod.scan_kernel_name(129, 768) and "qreg" in mod.scan_kernel_name(256, 700)   # 700 pads to 768
+    assert "bigq" in mod.scan_kernel_name(256, 1024) and "bigq" in mod.scan_kernel_name(256, 384)  # KT != 24
+
+
+def test_pmc_traffic_tool_doubles_fetch_and_filters_small_launches(tmp_path):
+    import importlib.util
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = "Dispatch_Id,Kernel_Name,Grid_Size,Counter_Name,Counter_Value\n"
+    f = tmp_path / "f.csv"
+    w = tmp_path / "w.csv"
+    f.write_text(hdr + "1,hbmrag::dense_scan_bigq_kernel<x>,131072,FETCH_SIZE,1000.0\n"
+                       "2,hbmrag::dense_scan_bigq_kernel<x>,131072,FETCH_SIZE,3000.0\n"
+                       "3,hbmrag::dense_scan_kernel<x>,512,FETCH_SIZE,10.0\n"
+                       "4,hbmrag::sparse_scan_kernel(a),1024,FETCH_SIZE,500.0\n")
+    w.write_text(hdr + "1,hbmrag::dense_scan_bigq_kernel<x>,131072,WRITE_SIZE,40.0\n"
+                       "4,hbmrag::sparse_scan_kernel(a),1024,WRITE_SIZE,8.0\n")
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "make_pmc_traffic.py"), str(f), str(w),
+                          "1000", "768", "128"], capture_output=True, text=True, check=True).stdout
+    d = json.loads(out)
+    dense = d["kernels"]["dense_scan"]
+    assert dense["launches_averaged"] == 1                       # 1000 KiB and 10 KiB launches are below half the largest
+    assert dense["fetch_bytes_per_launch"] == 2 * 3000.0 * 1024  # gfx950: FETCH_SIZE counts 128-B requests at 64 B
+    assert dense["write_bytes_per_launch"] == 40.0 * 1024
+    assert dense["algorithmic_bytes_per_launch"] == 1000 * 768 * 2 + 4 * 1000
+    assert d["kernels"]["sparse_scan"]["hbm_bytes_per_launch"] == (2 * 500.0 + 8.0) * 1024
