@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
     constexpr int L = T / NW;                     // tiles a wave loads per stage
     constexpr int TPS = kRowBlocksPerSuper * KT;  // tiles of one 64-row super-group, contiguous in the shard
     constexpr int H = 4;                          // tiles whose LDS reads are issued / awaited together
-    static_assert(KT % T == 0 && T % NW == 0 && T % H == 0, "whole stages per row block, the same number of tiles per wave and stage");
+    static_assert(KT % T == 0 && T % NW == 0 && T % H == 0 && (T / H) % L == 0, "whole stages per row block, the same number of tiles per wave and stage");
     static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
     __shared__ chunk_t ring[kRing * kTileChunks];
     __shared__ f32x4_t sc_lds[2][kSuperRows / 4];  // row scales of the current / next super-group
@@ -492,18 +492,24 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
     // loader: wave w brings tile w of every stage
     int64_t ld_sg = first;
     int ld_within = wid;
-    auto issue = [&](int stage_slot) {
+    // tile wid + l * NW of the stage the loader is at (all L of them lie inside the same super-group)
+    auto issue_one = [&](int stage_slot, int l) {
         const int64_t sg = ld_sg < n_super ? ld_sg : first;  // past the end: harmless re-read, keeps the count of loads in flight fixed
-        const chunk_t* src = tiles + (sg * TPS + ld_within) * kTileChunks + lane;
-#pragma unroll
-        for (int l = 0; l < L; ++l)  // tiles wid, wid + NW, ... of the stage (all inside the same super-group)
-            __builtin_amdgcn_global_load_lds((hr_gptr_t)(src + l * NW * kTileChunks),
-                                             (hr_lptr_t)(ring + (stage_slot * T + wid + l * NW) * kTileChunks), 16, 0, 2 /* nt: each byte is read once */);
+        const chunk_t* src = tiles + (sg * TPS + ld_within + l * NW) * kTileChunks + lane;
+        __builtin_amdgcn_global_load_lds((hr_gptr_t)src, (hr_lptr_t)(ring + (stage_slot * T + wid + l * NW) * kTileChunks), 16,
+                                         0, 2 /* nt: each byte is read once */);
+    };
+    auto advance_loader = [&]() {
         ld_within += T;
         if (ld_within >= TPS) {
             ld_within -= TPS;
             ld_sg += step;
         }
+    };
+    auto issue = [&](int stage_slot) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) issue_one(stage_slot, l);
+        advance_loader();
     };
     auto issue_scale = [&](int64_t sg, int slot) {  // wave 0 only: one more (older) operation on its counter
         const int64_t sgc = sg < n_super ? sg : first;
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
                 // own tiles of this stage have landed: at least (NS - 2) * L newer loads were issued after them
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * L) : "memory");
                 lds_barrier();
-                issue(st == 0 ? NS - 1 : st - 1);  // the slots of the stage everybody has just left
+                const int refill = st == 0 ? NS - 1 : st - 1;  // the slots of the stage everybody has just left
                 // LDS reads as inline asm: a ds_read the compiler can see after an LDS-DMA load makes it insert
                 // s_waitcnt vmcnt(0) ("may alias the DMA destination"), which would drain the ring every stage
                 const unsigned addr = ring_lds + (unsigned)(st * T * kTileChunks + lane) * 16u;
@@ -547,7 +553,10 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
 #pragma unroll
                         for (int gq = 0; gq < GW; ++gq)
                             Mfma<_Float16>::run(a[j], qf[gq][ph * T + half * H + j], acc[gq][j & 1]);
+                    // the stage's L refill loads are spread over the stage instead of issued in one burst
+                    if ((half + 1) % ((T / H) / L) == 0) issue_one(refill, (half + 1) / ((T / H) / L) - 1);
                 }
+                advance_loader();
                 st = (st + 1 == NS) ? 0 : st + 1;
             }
             // epilogue of the row block: lane holds rows quad*4..+3 of the block for query (lane & 15) of each group
