@@ -439,8 +439,8 @@ __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
 // The 64 row scales of the NEXT super-group travel the same way (one 256-byte LDS-DMA load by wave 0,
 // a whole super-group ahead): an ordinary register load inside the loop would make the compiler wait
 // for it with vmcnt(0), i.e. drain the ring.  Epilogue and output (per-group maxima) as in the other scans.
-// Measured at 10M x 768: 3.8 ms per 256 queries (4.04 TB/s) against 2 x 2.6 ms for two 128-query passes (stages of
-// 8 tiles, i.e. three barriers per row block: 4.0 ms).  The DMA stream alone (no LDS reads, no MFMAs) runs at
+// Measured at 10M x 768: 3.77 ms per 256 queries (4.09 TB/s) against 2 x 2.6 ms for two 128-query passes (stages of
+// 8 tiles, i.e. three barriers per row block: 4.0 ms; a stage's refill loads issued in one burst: 3.82 ms).  The DMA stream alone (no LDS reads, no MFMAs) runs at
 // 5.06 TB/s with nontemporal loads (4.3 TB/s without the hint; ring depth changes nothing), and the LDS reads
 // (8 waves x 1 KiB per tile, ~50 B/clk/CU) are what the rest of the time goes to.  A 128-query form (4 waves x 32 queries, two
 // blocks per CU) measures 2.63 ms alone and the same step time as dense_scan_bigq_kernel inside the pipeline, so
