@@ -36,6 +36,14 @@ from .embedding_cache import get_semantic_cache
 
 logger = logging.getLogger(__name__)
 
+# FLOAT fields of the collection schema (reference indexing.py:200-202) hold float32; a search hands them back as
+# Python floats of the float32-rounded value, which is what the payload columns store
+_FLOAT_FIELDS = ("entropy", "redundancy", "domain_density")
+
+
+def _f32(v) -> float:
+    return float(np.float32(v))
+
 
 class IndexType(Enum):
     SEMANTIC = "semantic"
@@ -260,9 +268,9 @@ class MilvusIndexManager:
                 c["content"].append(chunk.text[:65535])
                 c["chunk_index"].append(int(m.chunk_index))
                 c["token_count"].append(int(m.token_count))
-                c["entropy"].append(float(m.entropy))
-                c["redundancy"].append(float(m.redundancy))
-                c["domain_density"].append(float(m.domain_density))
+                c["entropy"].append(_f32(m.entropy))
+                c["redundancy"].append(_f32(m.redundancy))
+                c["domain_density"].append(_f32(m.domain_density))
                 c["timestamp"].append(str(m.timestamp))
                 c["metadata_json"].append(str(m.to_dict())[:10000])
             self._np_cols = None
@@ -292,7 +300,8 @@ class MilvusIndexManager:
                     "domain_density": lambda r: 0.0, "timestamp": lambda r: "", "metadata_json": lambda r: ""}
         for name, fn in defaults.items():
             given = scalar_columns.get(name)
-            c[name].extend(list(given) if given is not None else [fn(r) for r in range(n)])
+            vals = list(given) if given is not None else [fn(r) for r in range(n)]
+            c[name].extend([_f32(v) for v in vals] if name in _FLOAT_FIELDS else vals)
         self._np_cols = None
 
     def add_rows_synthetic(self, dense: np.ndarray, sparse_csr=None):

@@ -259,6 +259,7 @@ class HybridRetriever:
         fused: List[Dict[str, Any]] = []
         for doc_id, score, seen_in in self._rank_fusion(hit_lists, weights):
             hit = payload[doc_id]
+            hit.pop("_row", None)  # manager-internal row number (device rank fusion); not part of the reference's hit dict
             hit["score"] = score
             hit["retrieval_methods"] = [m for i, m in enumerate(_METHOD_ORDER) if i in seen_in]
             meta = hit.get("metadata")

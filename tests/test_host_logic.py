@@ -439,3 +439,47 @@ def test_pmc_traffic_tool_doubles_fetch_and_filters_small_launches(tmp_path):
     assert dense["write_bytes_per_launch"] == 40.0 * 1024
     assert dense["algorithmic_bytes_per_launch"] == 1000 * 768 * 2 + 4 * 1000
     assert d["kernels"]["sparse_scan"]["hbm_bytes_per_launch"] == (2 * 500.0 + 8.0) * 1024
+
+
+def test_search_hit_formatting_matches_reference_g6():
+    """Golden G6 (tests/golden/gen_golden_g6.py): the dicts the REFERENCE's MilvusIndexManager.search builds from
+    Milvus hits (reference indexing.py:533-551) — key order, id := chunk_id, the six metadata keys, float32-rounded
+    FLOAT fields — against this package's _format_hits fed the same rows and scores; plus the two ValueErrors of
+    indexing.py:466-467, :497-498 (same messages) and the default search params per collection (:472-484)."""
+    from advanced_rag.indexing import ShardCollection
+    g = gold("g6_search_format.json")
+    rows = g["rows"]
+    mgr = MilvusIndexManager(semantic_dim=g["dim"], sparse_dim=g["sparse_dim"], connect=False)
+    c = mgr._cols
+    for r in rows:
+        c["id"].append(r["chunk_id"])
+        for k in ("doc_id", "content", "chunk_index", "token_count", "timestamp", "metadata_json"):
+            c[k].append(r[k])
+        for k in ("entropy", "redundancy", "domain_density"):
+            c[k].append(float(np.float32(r[k])))
+    row_of = {r["chunk_id"]: i for i, r in enumerate(rows)}
+    for case in g["cases"]:
+        want = case["results"]
+        ids = np.array([row_of[w["id"]] for w in want] + [-1], dtype=np.int64)   # -1 padding ends a list
+        scores = np.array([w["score"] for w in want] + [0.0], dtype=np.float32)
+        got = mgr._format_hits(ids, scores)
+        assert len(got) == len(want)
+        for o, w in zip(got, want):
+            assert o.pop("_row") == row_of[w["id"]]
+            assert list(o) == list(w) == ["id", "content", "score", "metadata"]
+            assert list(o["metadata"]) == list(w["metadata"])
+            assert o == w, case["label"]  # scores round-trip through float32 exactly: they came from a float32
+        call = case["collection_search_call"]
+        if case["search_params"] is None:  # defaults chosen by collection kind
+            assert call["param"] == ({"metric_type": "IP"} if case["collection"] == "sparse_index"
+                                     else {"metric_type": "COSINE", "params": {"ef": 64}})
+    errs = {e["label"]: e for e in g["errors"]}
+    with pytest.raises(ValueError) as ei:
+        asyncio.run(mgr.search(np.zeros(4, np.float32), "nope"))
+    assert str(ei.value) == errs["unknown-collection"]["message"]
+    mgr.collections["sparse_index"] = ShardCollection(mgr, "sparse_index", "sparse", None, g["sparse_dim"], "IP")
+    with pytest.raises(ValueError) as ei:
+        asyncio.run(mgr.search(np.zeros(4, np.float32), "sparse_index"))
+    assert str(ei.value) == errs["sparse-bad-payload"]["message"]
+    mgr.collections.clear()
+    asyncio.run(mgr.close())

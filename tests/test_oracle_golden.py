@@ -110,3 +110,26 @@ def test_half_conversion_is_numpy_astype():
     v = (rng.standard_normal(4000) * 10.0 ** rng.integers(-9, 6, 4000)).astype(np.float32)
     v[:6] = [0.0, -0.0, 65504.0, 65520.0, 1e-8, 6.1e-5]
     assert np.array_equal(oracle.float_to_half_bits(v), v.astype(np.float16).view(np.uint16))
+
+
+def test_oracle_search_chain_reproduces_the_references_retrieve_on_config1():
+    """oracle.dense_search / oracle.sparse_search(drop 0.2) -> oracle.rrf on g5's inputs gives the ids
+    (bit-exact), the float64 fused scores (bit-equal: RRF depends only on ranks) and the method tags that the
+    REFERENCE's HybridRetriever.retrieve produced on BASELINE config 1 (reference retrieval.py:249-339,
+    :421-491 over an exact numpy FLAT collection; generated by tests/golden/gen_golden.py:159-219).  This ties
+    the oracle's dense/sparse ranking (k-ordered fp64, tie = lower row, drop rule) to reference-run output."""
+    import g5_data
+    g, X, (ptr, idx, val), Q, SQ = g5_data.inputs()
+    assert len(g["runs"]) == 16
+    kp, top_k = 40, 20
+    di, _ = oracle.dense_search(X, Q, kp, oracle.COSINE)
+    si, _ = oracle.sparse_search(ptr, idx, val, SQ, kp, 0.2)
+    names = ("semantic", "sparse", "domain")
+    for run in g["runs"]:
+        q = run["query"]
+        sparse_list = si[q][si[q] >= 0] if run["with_sparse"] else ()
+        ids, scores, methods = oracle.rrf(di[q], sparse_list, (), 0.7, 0.3, 0.2, 60)
+        ids, scores, methods = ids[:top_k], scores[:top_k], methods[:top_k]
+        assert [g5_data.row_id(int(r)) for r in ids] == run["ids"], (run["with_sparse"], q)
+        assert [float(s).hex() for s in scores] == run["scores"]
+        assert [sorted(n for bit, n in enumerate(names) if (int(m) >> bit) & 1) for m in methods] == run["methods"]
