@@ -480,6 +480,16 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     return HR_OK;
 }
 
+// Doc ranges one scan block walks (sparse_scan_kernel pipelines over them): as many as leave the chip
+// about six rounds of blocks (two blocks per CU), at most 16; gridDim.y must stay below 65536.
+int sparse_ranges_per_block(const hr_index* h, int B) {
+    static const int forced = [] { const char* e = std::getenv("HBMRAG_SPARSE_RPB"); return e ? std::atoi(e) : 0; }();
+    const int64_t pairs = (int64_t)B * h->n_ranges;
+    int64_t rpb = forced > 0 ? forced : std::min<int64_t>(16, pairs / (6 * 2 * (int64_t)h->cu_count));
+    rpb = std::max<int64_t>(rpb, (h->n_ranges + 65534) / 65535);
+    return (int)std::max<int64_t>(1, rpb);
+}
+
 int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64_t* d_qptr, const int32_t* d_qidx,
                           const float* d_qval, int B, int max_q_nnz, int k, const uint8_t* d_mask, int64_t* d_ids,
                           float* d_scores, int32_t* d_flags, int C, int phases = PHASE_ALL) {
@@ -503,15 +513,15 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
                            ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>());
         HIP_TRY(h, hipGetLastError());
     }
-    for (int q0 = 0; (phases & PHASE_SCAN) && q0 < B; q0 += 32768) {  // gridDim.y limit
-        const int nq = std::min(32768, B - q0);
+    if (phases & PHASE_SCAN) {
         Span sp(h, s, PH_SSCAN);
-        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)h->n_ranges, nq), dim3(kScanThreads), 0, s,
-                           h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(),
-                           h->post.as<uint32_t>(), ws->pq_n.as<int32_t>() + q0,
-                           ws->pq_idx.as<int32_t>() + (int64_t)q0 * stride, ws->pq_w.as<float>() + (int64_t)q0 * stride,
-                           stride, ws->qscale.as<float>() + q0, d_mask, h->n_sparse, n_groups, GR,
-                           ws->gmax.as<float>() + (int64_t)q0 * n_groups);
+        const int rpb = sparse_ranges_per_block(h, B);
+        const unsigned chunks = (unsigned)((h->n_ranges + rpb - 1) / rpb);
+        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)B, chunks), dim3(kScanThreads), 0, s,
+                           h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
+                           ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
+                           ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, rpb,
+                           ws->gmax.as<float>());
         HIP_TRY(h, hipGetLastError());
     }
     if (!(phases & PHASE_FINISH)) return HR_OK;
@@ -661,7 +671,7 @@ int build_sparse(hr_index* h) {
     const size_t off_bytes = (size_t)h->n_ranges * V1 * 4;
     HIP_TRY(h, h->rt_off.ensure(off_bytes));
     HIP_TRY(h, h->range_base.ensure((size_t)(h->n_ranges + 1) * 8));
-    HIP_TRY(h, h->post.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
+    HIP_TRY(h, h->post.ensure((size_t)nnz * 4 + 64));  // the scan fetches 16 bytes at a time: slack behind the last posting
     HIP_TRY(h, hipMemsetAsync(h->rt_off.p, 0, off_bytes, s));
     const unsigned doc_blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(sparse_count_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
@@ -1396,13 +1406,6 @@ int hr_set_profiling(hr_index* h, int enabled) {
     return HR_OK;
 }
 
-#ifdef HR_TRACE
-HR_API int hr_debug_trace(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hbmrag::hr_trace), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(hbmrag::hr_trace), z, sizeof(z)) != hipSuccess) return 1; }
-    return 0;
-}
-#endif
 int hr_last_kernel_ms(hr_index* h, float* out_ms, int n) {
     if (!h || !out_ms || n < 2 * PH_COUNT) return fail(h, HR_EINVAL, "need room for %d floats", 2 * PH_COUNT);
     DeviceGuard dg(h->device);

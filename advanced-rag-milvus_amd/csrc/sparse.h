@@ -59,16 +59,22 @@ __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int*
     }
 }
 
-// A posting is 4 bytes: fp16 weight (high half) | uint16 doc id local to the range.
+// A posting is 4 bytes: fp16 weight (high half) | uint16 accumulator slot of the doc inside its range.
 // The scan is only the candidate generator (the refine recomputes from the fp32
 // CSR), so the weight may be rounded; a positive weight never rounds to zero, so
 // "accumulator > 0  <=>  some positive product" still holds.
+// Accumulator slot of local doc d = d + d / 32: the scan's LDS accumulators carry one pad word per
+// 32 docs (conflict-free group-max reads), and storing the padded index here saves the scan two
+// instructions per posting.
+constexpr int kAccPadShift = 5;
+constexpr int kAccWords = kRangeDocs + (kRangeDocs >> kAccPadShift);
+__host__ __device__ inline int acc_slot(int local_doc) { return local_doc + (local_doc >> kAccPadShift); }
 __device__ inline uint32_t pack_posting(uint16_t local_doc, float w) {
     union { _Float16 h; unsigned short u; } cv;
     cv.h = (_Float16)w;  // round to nearest even
     unsigned short hb = cv.u;
     if ((hb & 0x7FFFu) == 0 && w != 0.f) hb = (unsigned short)((w < 0.f ? 0x8000u : 0u) | 1u);  // keep the sign, min subnormal
-    return ((uint32_t)hb << 16) | local_doc;
+    return ((uint32_t)hb << 16) | (uint32_t)acc_slot(local_doc);
 }
 __device__ inline float posting_weight(uint32_t p) {
     union { _Float16 h; unsigned short u; } cv;
@@ -99,10 +105,11 @@ __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int
 // The scan accumulates in 32-bit FIXED POINT (LDS integer atomics run ~4x the
 // rate of LDS float atomics on gfx950, and integer sums do not depend on the
 // order the waves arrive in).  With S = sum |w_q| and M = max |doc weight| every
-// partial sum is bounded by S*M, so scale = 2^30/(S*M) cannot overflow int32.
-// Each contribution is rounded AWAY from zero (a positive product always counts
-// at least 1), hence |fixed/scale - exact| <= (nnz+1)/scale: that bound is
-// written to q_eps for the exactness check of select_topk.
+// partial sum is bounded by S*M, so scale = 2^30/(S*M) leaves int32 a factor 2 of headroom.
+// A posting contributes trunc(product * scale + 1): never below the exact value, at most 1 above it for
+// products >= -1/scale and less than 2 above it otherwise, and a positive product always counts at
+// least 1.  Hence 0 <= fixed/scale - exact < 2 * nnz / scale: that bound (with nnz + 1) is written to
+// q_eps for the exactness check of select_topk.
 // It also re-lays the CSR queries out at a fixed stride (pq_idx / pq_w = weight*scale, zero padded,
 // pq_n = term count), so a scan block can fetch its query's terms without first waiting for q_indptr:
 // one dependent round trip less per block.
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
                                                                 float* __restrict__ q_eps, int32_t* __restrict__ pq_n,
                                                                 int32_t* __restrict__ pq_idx,
                                                                 float* __restrict__ pq_w) {
-    // q_eps = absolute part of the scan's error bound: fixed-point rounding (nnz+1)/scale plus the
+    // q_eps = absolute part of the scan's error bound: fixed-point rounding 2*(nnz+1)/scale plus the
     // fp16 floor of tiny doc weights (6e-8 per unit of query weight); the relative part (fp16
     // rounding of normal weights, 2^-11) is passed to select_topk as eps_rel.
     __shared__ float part[256];
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
         // a query longer than the caller's max_q_nnz would be truncated by the fixed-stride layout: make its
         // list "never proven" so it is redone through the host form
         q_eps[qi] = (t1 - t0 > stride) ? __builtin_inff()
-                                       : (scale > 0.f ? (float)(t1 - t0 + 1) / scale + part[0] * 6.0e-8f : 0.f);
+                                       : (scale > 0.f ? 2.0f * (float)(t1 - t0 + 1) / scale + part[0] * 6.0e-8f : 0.f);
         pq_n[qi] = (int32_t)min((int64_t)stride, t1 - t0);
     }
     for (int i = tid; i < stride; i += 256) {
@@ -144,180 +151,272 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
     }
 }
 
-// ---- scan: grid (n_ranges, B), 1024 threads -------------------------------------
-// The block owns docs [range*16384, +16384) of one query: accumulators live in
-// LDS (64 KiB; two blocks per CU), every posting of the query's terms inside
-// the range is applied with an LDS integer atomic, and only the per-64-doc
-// maxima leave the CU.  Work is cut into items of kItemPostings consecutive
-// postings of one run; each wave takes items in a strided loop, kItemsInFlight
-// at a time, so it keeps 16 independent coalesced loads in flight instead of one
-// (a typical (query, range) — 80 runs of ~164 postings = ~240 items — is then ONE round trip).
-// Algorithmic HBM bytes per (query, range): sum over query terms of run_len * 4
-// (packed uint16 doc + fp16 weight) + 2*4 per term for the run bounds + group maxima out.
-constexpr int kScanThreads = 1024;
-constexpr int kDocsPerThread = kRangeDocs / kScanThreads;  // consecutive docs one thread reduces in the group-max pass (16 or 32)
+// ---- scan, pipelined over ranges: grid (B, ceil(n_ranges / rpb)), 512 threads, two blocks per CU ----
+// The block owns ONE query over `rpb` consecutive doc ranges.  Accumulators for one range (16 384
+// docs) live in LDS; every posting of the query's terms inside the range is applied with an LDS
+// integer atomic, and only the per-group maxima leave the CU.  The ranges are walked as a software
+// pipeline, so that posting loads are in flight all the time:
+//   * P stage (wave 0, lane = 4 term slots): the query's terms are fetched once per block; the run
+//     bounds (rt_off lookups) and the posting-block base of the NEXT range are requested when the
+//     bounds of the current one start being consumed, a whole range ahead;
+//   * T stage (wave 0): bounds -> slot table of one STEP.  A slot is 64 consecutive postings of one
+//     run, served by 16 lanes with one 16-byte load each; a step is as many whole runs as fit
+//     kSlots slots (greedy), so a short query needs one step per range and a long or skewed one
+//     (a df = 50 % term is a run of 8 192 postings = 128 slots) simply takes more steps — there is
+//     no second code path.  T(s+2) is built while step s is applied;
+//   * L stage (all waves): wave w owns items w, w + 8, ... (an item = 4 slots = one load instruction);
+//     it keeps K items in registers and, right after applying item u of step s, re-issues that
+//     register quad for item u of step s+1: the loads of the next step fly under this step's LDS
+//     atomics, the group maxima, the zeroing and both barriers;
+//   * group maxima and zeroing are one pass (a thread zeroes the words it has just reduced).
+// blockIdx.x = query: blocks that run together work on the same ranges, so the run-bound lookups (a
+// 40 KB row per range) and the postings of shared terms are served by L2 / the Infinity Cache.
+// Round 1's form (one block per (range, query), every fetch on the block's critical path) ran at
+// 0.30 of the HBM peak; an intermediate form of this pipeline with 256-posting items and ~30
+// instructions per posting was instruction-issue bound (no posting loads at all: 0.30 ms of 0.37 ms
+// at 2.5M docs, B = 128), which is why a posting now costs 7 vector instructions.
+// Algorithmic HBM bytes per (query, range): sum over query terms of run_len * 4 (packed uint16 slot +
+// fp16 weight) + 2*4 per term for the run bounds + group maxima out.
+constexpr int kScanThreads = 512;
 constexpr int kScanWaves = kScanThreads / 64;
-constexpr int kItemPostings = 64;
-constexpr int kItemsInFlight = 16;
-constexpr int kItemTable = 4096;  // items whose run is looked up from a table instead of searched
+constexpr int kScanK = 8;                               // items a wave keeps in flight
+constexpr int kSlotPostings = 64;                       // postings per slot (16 lanes x 4)
+constexpr int kSlots = kScanK * kScanWaves * 4;         // slots per step = everything one round of loads covers
+constexpr int kDocsPerThread = kRangeDocs / kScanThreads;  // consecutive docs a thread reduces in the group-max pass
+static_assert(kDocsPerThread == 32 && (1 << kAccPadShift) == kDocsPerThread, "one pad word per thread slice");
+static_assert(kSlots >= kRangeDocs / kSlotPostings, "the longest possible run must fit an empty slot table");
 
-__device__ inline int fixed_contrib(float p) {  // round away from zero, branch-free
-    const int a = __float2int_ru(fabsf(p));
-    return p < 0.f ? -a : a;
-}
-// Accumulator index with one pad word per 16 docs: the per-group maxima (one
-// thread per 16 docs, stride 17 words) then read conflict-free.
-__device__ inline int acc_index(int d) { return d + (d >> 4); }
+struct ScanTab {
+    float w[kScanTermChunk];  // per run (term slot of the chunk): query weight * fixed-point scale
+    unsigned e0[kSlots];      // per slot: first posting, relative to the range's block
+    unsigned cr[kSlots];      // per slot: postings << 8 | run
+    unsigned long long base;  // first posting of the range's block
+    int n_slots;              // slots in use
+    int range;                // range - r0
+    int range_done;           // this step completes its range: group maxima follow
+    int end;                  // no such step: the block is done
+};
 
-#ifdef HR_TRACE
-__device__ unsigned long long hr_trace[16];
-#define TR(i) do { if (tid == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(&hr_trace[i], t_ - tr_last); tr_last = t_; } } while (0)
-#define TRWAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
-#else
-#define TR(i)
-#define TRWAIT()
-#endif
-__global__ __launch_bounds__(kScanThreads) void sparse_scan_kernel(
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load at 4-byte alignment
+
+__global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_kernel(
     const unsigned int* __restrict__ rt_off, int64_t V1, const int64_t* __restrict__ range_base,
-    const uint32_t* __restrict__ post,
-    const int32_t* __restrict__ pq_n, const int32_t* __restrict__ pq_idx, const float* __restrict__ pq_w,
-    int stride, const float* __restrict__ q_scale, const uint8_t* __restrict__ rowmask,
-    int64_t n_docs, int64_t n_groups, int group_docs, float* __restrict__ gmax) {
-    __shared__ int acc[kRangeDocs + kRangeDocs / 16];
-    __shared__ uint8_t item_run[kItemTable];
-    __shared__ unsigned int run_lo[kScanTermChunk], run_hi[kScanTermChunk];
-    __shared__ unsigned int item_pre[kScanTermChunk + 1];  // exclusive prefix of items per run
-    __shared__ float run_w[kScanTermChunk];
-    __shared__ unsigned int wsum[16];
-    const int64_t range = blockIdx.x;
-    const int qi = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef HR_TRACE
-    unsigned long long tr_last = __builtin_amdgcn_s_memtime();
-    if (tid == 0) atomicAdd(&hr_trace[15], 1ull);
-#endif
+    const uint32_t* __restrict__ post, const int32_t* __restrict__ pq_n, const int32_t* __restrict__ pq_idx,
+    const float* __restrict__ pq_w, int stride, const float* __restrict__ q_scale,
+    const uint8_t* __restrict__ rowmask, int64_t n_docs, int64_t n_groups, int group_docs, int64_t n_ranges,
+    int rpb, float* __restrict__ gmax) {
+    constexpr int K = kScanK, NW = kScanWaves, DPT = kDocsPerThread;
+    __shared__ int acc[kAccWords];
+    __shared__ ScanTab tab[2];  // T(s) lives in tab[s & 1]
+    const int qi = blockIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rpb;
+    const int n_r = (int)min((int64_t)rpb, n_ranges - r0);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
         int4* a4 = reinterpret_cast<int4*>(acc);
-        for (int i = tid; i < (kRangeDocs + kRangeDocs / 16) / 4; i += kScanThreads) a4[i] = make_int4(0, 0, 0, 0);
+        for (int i = tid; i < kAccWords / 4; i += kScanThreads) a4[i] = make_int4(0, 0, 0, 0);
     }
-    TRWAIT(); TR(0);
-    const unsigned int* offs = rt_off + range * V1;
-    const uint32_t* pp = post + range_base[range];
-    // every load below is independent of the others except run bounds <- term: two round trips, not three
-    const int n_terms = pq_n[qi];
-    const float scale = q_scale[qi];
-    const int32_t* my_idx = pq_idx + (int64_t)qi * stride;
-    const float* my_w = pq_w + (int64_t)qi * stride;
 
-    for (int tc = 0; tc == 0 || tc < n_terms; tc += kScanTermChunk) {
-        // speculative fetch: slots past the query's length hold term 0 / weight 0 (padding written by the prep)
-        const bool slot = tid < kScanTermChunk && tc + tid < stride;
-        const int32_t t = slot ? my_idx[tc + tid] : 0;
-        const float wq = slot ? my_w[tc + tid] : 0.f;
-        TRWAIT(); TR(1);
-        const unsigned int lo = slot ? offs[t] : 0u, hi = slot ? offs[t + 1] : 0u;
-        const int nt = min(kScanTermChunk, max(n_terms - tc, 0));
-        TRWAIT(); TR(2);
-        if (tc) __syncthreads();  // the run tables of the previous chunk are still being read
-        const unsigned int items = tid < nt ? (hi - lo + kItemPostings - 1) / kItemPostings : 0u;
-        // exclusive scan of `items` over the first 256 threads (4 waves)
-        unsigned int x = items;
+    // ---- P / T stages: wave 0 only.  A "unit" is (range, chunk of 256 query terms); lane l owns term slots 4l .. 4l+3.
+    const int n_terms = pq_n[qi];
+    const int n_chunks = max(1, (n_terms + kScanTermChunk - 1) / kScanTermChunk);
+    const int G = n_r * n_chunks;  // units of this block
+    int t4[4] = {0, 0, 0, 0};
+    float wc[4] = {0.f, 0.f, 0.f, 0.f}, wn[4] = {0.f, 0.f, 0.f, 0.f};          // weights of the current / next unit
+    unsigned loc[4] = {0, 0, 0, 0}, hic[4] = {0, 0, 0, 0}, lon[4] = {0, 0, 0, 0}, hin[4] = {0, 0, 0, 0};  // run bounds
+    unsigned long long base_c = 0, base_n = 0;                                // posting-block base of the unit's range
+    int g_cur = 0, p_pos = 0;  // unit being consumed, first term slot of it not yet in a step
+    auto p_terms = [&](int chunk, float (&w)[4]) {  // the chunk's term ids and scaled weights (slots past the query hold 0 / 0.f)
+        const int slot = chunk * kScanTermChunk + 4 * lane;
+        int4 ti = make_int4(0, 0, 0, 0);
+        float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (slot < stride) {
+            ti = *reinterpret_cast<const int4*>(pq_idx + (int64_t)qi * stride + slot);
+            tw = *reinterpret_cast<const float4*>(pq_w + (int64_t)qi * stride + slot);
+        }
+        t4[0] = ti.x; t4[1] = ti.y; t4[2] = ti.z; t4[3] = ti.w;
+        w[0] = tw.x; w[1] = tw.y; w[2] = tw.z; w[3] = tw.w;
+    };
+    auto p_issue = [&](int g, unsigned (&lo)[4], unsigned (&hi)[4], float (&w)[4], unsigned long long& base) {
+        const int range = g / n_chunks, chunk = g - range * n_chunks;
+        if (n_chunks > 1) p_terms(chunk, w);
+        const unsigned int* offs = rt_off + (r0 + range) * V1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[j] = offs[t4[j]];
+            hi[j] = offs[t4[j] + 1];
+        }
+        base = (unsigned long long)range_base[r0 + range];
+    };
+    auto p_build = [&](ScanTab& T) {  // the next step: as many whole runs of the current unit as fit the slot table
+        if (g_cur >= G) {
+            if (lane == 0) { T.n_slots = 0; T.range_done = 0; T.end = 1; T.base = 0; }  // base 0: the refill of an empty step still reads valid bytes
+            return;
+        }
+        const int range = g_cur / n_chunks, chunk = g_cur - range * n_chunks;
+        const int nt = min(kScanTermChunk, max(n_terms - chunk * kScanTermChunk, 0));
+        unsigned cnt[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = 4 * lane + j;
+            cnt[j] = (t >= p_pos && t < nt) ? (hic[j] - loc[j] + kSlotPostings - 1) / kSlotPostings : 0u;
+            mine += cnt[j];
+        }
+        unsigned incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            unsigned int y = __shfl_up(x, off);
-            if (lane >= off) x += y;
+            const unsigned y = __shfl_up(incl, off);
+            if (lane >= off) incl += y;
         }
-        if (lane == 63) wsum[wave] = x;
-        __syncthreads();
-        if (tid < kScanTermChunk) {
-            unsigned int wbase = 0;
-            for (int j = 0; j < wave; ++j) wbase += wsum[j];
-            const unsigned int first = wbase + x - items;
-            item_pre[tid] = first;
-            if (tid == kScanTermChunk - 1) item_pre[kScanTermChunk] = wbase + x;
-            if (tid < nt) {
-                run_lo[tid] = lo;
-                run_hi[tid] = hi;
-                run_w[tid] = wq;
-                // run of each of the first kItemTable items
-                for (unsigned int c = 0; c < items && first + c < kItemTable; ++c) item_run[first + c] = (uint8_t)tid;
+        unsigned first = incl - mine;
+        int taken = 0;           // term slots of this lane that go into the step
+        unsigned used = 0;       // slots in use after this lane's runs
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = 4 * lane + j;
+            const bool fits = t >= p_pos && t < nt && first + cnt[j] <= (unsigned)kSlots;
+            if (fits) {
+                T.w[t] = wc[j];
+                unsigned e = loc[j];
+#pragma unroll 1
+                for (unsigned c = 0; c < cnt[j]; ++c, e += kSlotPostings) {
+                    T.e0[first + c] = e;
+                    T.cr[first + c] = (min((unsigned)kSlotPostings, hic[j] - e) << 8) | (unsigned)t;
+                }
+                ++taken;
+                used = first + cnt[j];
             }
+            first += cnt[j];
         }
-        __syncthreads();
-        const unsigned int total_items = item_pre[kScanTermChunk];
-        TR(3);
+        // the prefix is monotone, so the runs that fit are exactly the first ones
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            taken += __shfl_xor(taken, off);
+            used = max(used, (unsigned)__shfl_xor((int)used, off));
+        }
+        const int p_end = p_pos + taken;
+        const bool unit_done = p_end >= nt;
+        if (lane == 0) {
+            T.n_slots = (int)used;
+            T.range = range;
+            T.base = base_c;
+            T.range_done = unit_done && chunk == n_chunks - 1;
+            T.end = 0;
+        }
+        p_pos = p_end;
+        if (unit_done) {  // on to the next unit; request the bounds of the one after it
+            ++g_cur;
+            p_pos = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { loc[j] = lon[j]; hic[j] = hin[j]; wc[j] = wn[j]; }
+            base_c = base_n;
+            if (g_cur + 1 < G) p_issue(g_cur + 1, lon, hin, wn, base_n);
+        }
+    };
 
-        for (unsigned int base = wave; base < total_items; base += kScanWaves * kItemsInFlight) {
-            uint32_t pk[kItemsInFlight];
-            int rr[kItemsInFlight];
+    // ---- L stage: lane group q = lane / 16 serves slot 4 * item + q with one 16-byte load per lane
+    const int sub = lane >> 4, l16 = lane & 15;
+    auto load_item = [&](const ScanTab& T, const uint32_t* pp, int item) -> u32x4_a4 {
+        const int slot = 4 * item + sub;
+        const unsigned n = slot < T.n_slots ? T.cr[slot] >> 8 : 0u;
+        // lanes with nothing to fetch read the block's first 16 bytes: no branch around the load
+        const uint32_t* a = (unsigned)(4 * l16) < n ? pp + T.e0[slot] + 4 * l16 : pp;
+#if defined(HR_ABLATE) && HR_ABLATE == 2  // timing-only build: no posting loads, synthetic postings instead
+        const unsigned x = (T.e0[slot] + 4 * l16) * 2654435761u;
+        return (u32x4_a4){(x >> 7 & 0x3FFFu) | 0x3C000000u, (x >> 11 & 0x3FFFu) | 0x3C000000u, (x >> 5 & 0x3FFFu) | 0x3C000000u, (x >> 13 & 0x3FFFu) | 0x3C000000u};
+#else
+        return *reinterpret_cast<const u32x4_a4*>(a);
+#endif
+    };
+    auto apply_item = [&](const ScanTab& T, int item, const u32x4_a4& v) {
+        const int slot = 4 * item + sub;
+        const unsigned cr = slot < T.n_slots ? T.cr[slot] : 0u;
+        const int n_valid = (int)(cr >> 8) - 4 * l16;
+        const float wr = T.w[cr & 255u];
 #pragma unroll
-            for (int u = 0; u < kItemsInFlight; ++u) {  // every load is issued before the first use
-                const unsigned int item = base + kScanWaves * u;
-                rr[u] = 0;
-                pk[u] = 0u;
-                if (item < total_items) {
-                    int r;
-                    if (item < kItemTable) {
-                        r = item_run[item];
-                    } else {  // largest r with item_pre[r] <= item (wave-uniform)
-                        r = 0;
-                        int top = nt - 1;
-                        while (r < top) {
-                            const int mid = (r + top + 1) >> 1;
-                            if (item_pre[mid] <= item) r = mid; else top = mid - 1;
-                        }
-                    }
-                    const unsigned int e = run_lo[r] + (item - item_pre[r]) * kItemPostings + lane;
-                    rr[u] = r;
-                    if (e < run_hi[r]) pk[u] = pp[e];
-                }
-            }
-            TRWAIT(); TR(4);
-#pragma unroll
-            for (int u = 0; u < kItemsInFlight; ++u)  // weight bits 0 = no posting (or a zero weight): nothing to add
-                if (pk[u] >> 16) atomicAdd(&acc[acc_index((int)(pk[u] & 0xFFFFu))], fixed_contrib(run_w[rr[u]] * posting_weight(pk[u])));
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t p = v[j];
+            const int c = (int)fmaf(posting_weight(p), wr, 1.0f);  // trunc(product + 1): see sparse_query_prep_kernel
+#if defined(HR_ABLATE) && HR_ABLATE == 1  // timing-only build: postings are fetched but not applied
+            if (j < n_valid) asm volatile("" ::"v"(c), "v"(p & 0xFFFFu));
+#else
+            if (j < n_valid) atomicAdd(&acc[p & 0xFFFFu], c);
+#endif
         }
+    };
+
+    // ---- prologue: T(0), T(1), round-0 items of step 0 in flight
+    if (wave == 0) {
+        if (n_chunks == 1) {
+            p_terms(0, wc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wn[j] = wc[j];
+        }
+        p_issue(0, loc, hic, wc, base_c);
+        if (G > 1) p_issue(1, lon, hin, wn, base_n);
+#pragma unroll 1
+        for (int i = 0; i < 2; ++i) p_build(tab[i]);
     }
-    TRWAIT(); TR(5);
     __syncthreads();
-    TR(6);
-    // per-group maxima: every thread reduces 16 consecutive docs; 64-doc groups
-    // finish with a 4-lane reduction
+    u32x4_a4 pk[K];
     {
-        int m[kDocsPerThread / 16];
-        const int64_t doc0 = range * kRangeDocs + (int64_t)tid * kDocsPerThread;
+        const uint32_t* pp0 = post + tab[0].base;
 #pragma unroll
-        for (int c = 0; c < kDocsPerThread / 16; ++c) {
-            m[c] = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                int v = acc[acc_index(tid * kDocsPerThread + c * 16 + j)];
-                if (rowmask) {
-                    const int64_t dd = doc0 + c * 16 + j;
-                    if (dd < n_docs && !((rowmask[dd >> 3] >> (dd & 7)) & 1)) v = 0;
-                }
-                m[c] = max(m[c], v);
-            }
-        }
-        const float inv = scale > 0.f ? 1.0f / scale : 0.f;
-        if (group_docs == 16) {
-#pragma unroll
-            for (int c = 0; c < kDocsPerThread / 16; ++c) {
-                const int64_t group = range * (kRangeDocs / 16) + tid * (kDocsPerThread / 16) + c;
-                if (group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)m[c] * inv;
-            }
-        } else {
-            int mm = m[0];
-#pragma unroll
-            for (int c = 1; c < kDocsPerThread / 16; ++c) mm = max(mm, m[c]);
-            constexpr int kLanesPerGroup = 64 / kDocsPerThread;  // 4 or 2
-#pragma unroll
-            for (int off = 1; off < kLanesPerGroup; off <<= 1) mm = max(mm, __shfl_xor(mm, off));
-            const int64_t group = range * (kRangeDocs / 64) + tid / kLanesPerGroup;
-            if (tid % kLanesPerGroup == 0 && group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)mm * inv;
-        }
+        for (int u = 0; u < K; ++u) pk[u] = load_item(tab[0], pp0, wave + NW * u);
     }
-    TRWAIT(); TR(7);
+    const float scale = q_scale[qi];
+    const float inv = scale > 0.f ? 1.0f / scale : 0.f;
+#pragma unroll 1
+    for (int s = 0;; ++s) {
+        const ScanTab& Tc = tab[s & 1];
+        const ScanTab& Tn = tab[(s + 1) & 1];
+        if (Tc.end) break;
+        const int n_c = Tc.n_slots;
+        const bool range_done = Tc.range_done != 0;
+        const int64_t range = r0 + Tc.range;
+        const uint32_t* pp_n = post + Tn.base;
+        // apply item u of step s, refill the quad with item u of step s+1
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+            const int item = wave + NW * u;
+            if (4 * item < n_c) apply_item(Tc, item, pk[u]);
+            pk[u] = load_item(Tn, pp_n, item);  // unconditional (an item past the step reads the block's first bytes): no branch around the load
+        }
+        __syncthreads();  // every posting of step s is in the accumulators; T(s) is free
+        if (wave == 0) p_build(tab[s & 1]);  // T(s+2)
+        if (range_done) {
+            // per-group maxima of the finished range, and zero for the next one: a thread owns DPT consecutive docs
+            const int64_t doc0 = range * kRangeDocs + (int64_t)tid * DPT;
+            unsigned alive = 0xFFFFFFFFu;  // filter bits of the thread's docs (bit i = doc0 + i)
+            if (rowmask) {
+                alive = 0u;
+#pragma unroll
+                for (int b = 0; b < DPT / 8; ++b)  // docs past the shard have empty accumulators: their bits do not matter
+                    alive |= (doc0 + 8 * b < n_docs ? (unsigned)rowmask[(doc0 >> 3) + b] : 0u) << (8 * b);
+            }
+            int* mine = acc + tid * (DPT + 1);
+            int m0 = 0, m1 = 0;  // maxima of docs 0..15 / 16..31 of the thread's slice
+#pragma unroll
+            for (int i = 0; i < DPT; ++i) {
+                int v = mine[i];
+                mine[i] = 0;
+                v = (alive >> i) & 1u ? v : 0;
+                if (i < 16) m0 = max(m0, v); else m1 = max(m1, v);
+            }
+            if (group_docs == 16) {
+                const int64_t group = range * (kRangeDocs / 16) + tid * (DPT / 16);
+                if (group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)m0 * inv;
+                if (group + 1 < n_groups) gmax[(int64_t)qi * n_groups + group + 1] = (float)m1 * inv;
+            } else {
+                int mm = max(m0, m1);
+                mm = max(mm, __shfl_xor(mm, 1));  // 64-doc group = two threads
+                const int64_t group = range * (kRangeDocs / 64) + (tid >> 1);
+                if ((tid & 1) == 0 && group < n_groups) gmax[(int64_t)qi * n_groups + group] = (float)mm * inv;
+            }
+        }
+        __syncthreads();  // zeroed accumulators and T(s+2) are visible
+    }
 }
 
 // ---- refine: one WAVE per candidate doc at a time (group_docs = 16 or 64 docs per group) ----
