@@ -112,7 +112,8 @@ struct hr_index {
     std::vector<float> h_val;
     int64_t n_sparse = 0, n_sparse_built = -1;
     float max_sparse_abs = 0.f;  // max |doc weight|: bounds the scan's fixed-point range
-    DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post;  // post: packed (fp16 weight | u16 doc)
+    DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post;  // post: packed (fp16 weight | u16 accumulator slot)
+    DevBuf idle_post;  // 64 x 4 idle postings: what scan lanes with nothing to fetch read (sparse.h)
     int64_t n_ranges = 0;
 
     bool finalized = false;
@@ -521,7 +522,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
                            h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
                            ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
                            ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, rpb,
-                           ws->gmax.as<float>());
+                           h->idle_post.as<uint32_t>(), ws->gmax.as<float>());
         HIP_TRY(h, hipGetLastError());
     }
     if (!(phases & PHASE_FINISH)) return HR_OK;
@@ -671,36 +672,40 @@ int build_sparse(hr_index* h) {
     const size_t off_bytes = (size_t)h->n_ranges * V1 * 4;
     HIP_TRY(h, h->rt_off.ensure(off_bytes));
     HIP_TRY(h, h->range_base.ensure((size_t)(h->n_ranges + 1) * 8));
-    HIP_TRY(h, h->post.ensure((size_t)nnz * 4 + 64));  // the scan fetches 16 bytes at a time: slack behind the last posting
     HIP_TRY(h, hipMemsetAsync(h->rt_off.p, 0, off_bytes, s));
     const unsigned doc_blocks = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(sparse_count_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
                        h->s_idx.as<int32_t>(), n, V1, h->rt_off.as<unsigned int>());
     HIP_TRY(h, hipGetLastError());
-    DevBuf totals, cursor;
-    HIP_TRY(h, totals.ensure((size_t)h->n_ranges * 8));
+    struct Scratch {  // released on every return path
+        DevBuf totals, cursor;
+        ~Scratch() { totals.release(); cursor.release(); }
+    } tmp;
+    HIP_TRY(h, tmp.totals.ensure((size_t)h->n_ranges * 8));
     hipLaunchKernelGGL(sparse_scan_offsets_kernel, dim3((unsigned)h->n_ranges), dim3(1024), 0, s,
-                       h->rt_off.as<unsigned int>(), V1, totals.as<unsigned long long>());
+                       h->rt_off.as<unsigned int>(), V1, tmp.totals.as<unsigned long long>());
     HIP_TRY(h, hipGetLastError());
     std::vector<unsigned long long> ht(h->n_ranges);
-    HIP_TRY(h, hipMemcpyAsync(ht.data(), totals.p, (size_t)h->n_ranges * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpyAsync(ht.data(), tmp.totals.p, (size_t)h->n_ranges * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     std::vector<int64_t> base(h->n_ranges + 1, 0);
     for (int64_t r = 0; r < h->n_ranges; ++r) base[r + 1] = base[r] + (int64_t)ht[r];
+    // runs are padded to 4 postings (filler postings): at most 3 more per (range, term) that occurs
+    HIP_TRY(h, h->post.ensure((size_t)base[h->n_ranges] * 4 + 64));  // + slack: the scan fetches 16 bytes at a time
     HIP_TRY(h, hipMemcpyAsync(h->range_base.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, s));
-    hipError_t e = cursor.ensure(off_bytes);
-    if (e != hipSuccess) {
-        totals.release();
-        return fail(h, HR_ENOMEM, "sparse build cursor: %s", hipGetErrorString(e));
-    }
-    HIP_TRY(h, hipMemcpyAsync(cursor.p, h->rt_off.p, off_bytes, hipMemcpyDeviceToDevice, s));
+    hipError_t e = tmp.cursor.ensure(off_bytes);
+    if (e != hipSuccess) return fail(h, HR_ENOMEM, "sparse build cursor: %s", hipGetErrorString(e));
+    HIP_TRY(h, hipMemcpyAsync(tmp.cursor.p, h->rt_off.p, off_bytes, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(sparse_fill_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
-                       h->s_idx.as<int32_t>(), h->s_val.as<float>(), n, V1, cursor.as<unsigned int>(),
+                       h->s_idx.as<int32_t>(), h->s_val.as<float>(), n, V1, tmp.cursor.as<unsigned int>(),
+                       h->range_base.as<int64_t>(), h->post.as<uint32_t>());
+    HIP_TRY(h, hipGetLastError());
+    const int64_t pairs = h->n_ranges * h->sparse_dim;
+    hipLaunchKernelGGL(sparse_pad_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
+                       h->rt_off.as<unsigned int>(), tmp.cursor.as<unsigned int>(), V1, h->n_ranges,
                        h->range_base.as<int64_t>(), h->post.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
-    totals.release();
-    cursor.release();
     h->n_sparse_built = n;
     return HR_OK;
 }
@@ -754,8 +759,12 @@ int hr_create(int device, int64_t dim, int dtype, int metric, int64_t sparse_dim
     DeviceGuard dg(device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->cu_count = prop.multiProcessorCount;
+    uint32_t idle[256];  // idle postings of scan lane l: weight 0, accumulator pad word l
+    for (unsigned l = 0; l < 256; ++l) idle[l] = filler_posting(l / 4);
     if (hipStreamCreateWithFlags(&h->ingest_stream, hipStreamNonBlocking) != hipSuccess ||
-        h->max_norm.ensure(4) != hipSuccess || hipMemset(h->max_norm.p, 0, 4) != hipSuccess) {
+        h->max_norm.ensure(4) != hipSuccess || hipMemset(h->max_norm.p, 0, 4) != hipSuccess ||
+        h->idle_post.ensure(sizeof idle) != hipSuccess ||
+        hipMemcpy(h->idle_post.p, idle, sizeof idle, hipMemcpyHostToDevice) != hipSuccess) {
         int rc = fail(nullptr, HR_EHIP, "device %d initialisation failed: %s", device, hipGetErrorString(hipGetLastError()));
         delete h;
         return rc;
@@ -777,7 +786,7 @@ void hr_destroy(hr_index* h) {
         for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
         for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
         for (DevBuf* b : {&h->tiles, &h->scale, &h->norm2, &h->max_norm, &h->stage, &h->s_indptr, &h->s_idx, &h->s_val,
-                          &h->rt_off, &h->range_base, &h->post})
+                          &h->rt_off, &h->range_base, &h->post, &h->idle_post})
             b->release();
         if (h->ingest_stream) (void)hipStreamDestroy(h->ingest_stream);
     }

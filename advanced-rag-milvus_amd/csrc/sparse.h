@@ -24,7 +24,9 @@ __global__ void sparse_count_kernel(const int64_t* __restrict__ indptr, const in
     for (int64_t e = indptr[d]; e < indptr[d + 1]; ++e) atomicAdd(&row[idx[e]], 1u);
 }
 
-// One block per range: in-place exclusive scan of V counts; slot V gets the total.
+// One block per range: in-place exclusive scan of the V run lengths, each rounded up to a multiple of
+// 4 postings (the scan fetches 16 bytes per lane and applies all four without a validity test; the
+// round-up slots hold filler postings, see sparse_pad_kernel); slot V gets the total.
 __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int* __restrict__ rt_off, int64_t V1,
                                                                    unsigned long long* __restrict__ range_total) {
     __shared__ unsigned int wsum[16];
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int*
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t base = 0; base < V; base += blockDim.x) {
         int64_t i = base + threadIdx.x;
-        unsigned int v = (i < V) ? row[i] : 0u;
+        unsigned int v = (i < V) ? (row[i] + 3u) & ~3u : 0u;
         unsigned int x = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -99,6 +101,20 @@ __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int
         unsigned int slot = atomicAdd(&cur[idx[e]], 1u);
         post[base + slot] = pack_posting(local, val[e]);
     }
+}
+
+// Filler postings behind the last real posting of every run (up to 3): weight 0, aimed at one of the
+// accumulators' pad words, which nobody reads.  cursor = where sparse_fill_kernel stopped.
+__device__ __host__ inline uint32_t filler_posting(unsigned int k) { return (uint32_t)(33u * (k & 511u) + 32u); }
+__global__ void sparse_pad_kernel(const unsigned int* __restrict__ rt_off, const unsigned int* __restrict__ cursor,
+                                  int64_t V1, int64_t n_ranges, const int64_t* __restrict__ range_base,
+                                  uint32_t* __restrict__ post) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (range, term)
+    const int64_t V = V1 - 1;
+    if (i >= n_ranges * V) return;
+    const int64_t range = i / V, t = i - range * V;
+    const unsigned int end = rt_off[range * V1 + t + 1];
+    for (unsigned int p = cursor[range * V1 + t]; p < end; ++p) post[range_base[range] + p] = filler_posting((unsigned int)t);
 }
 
 // ---- query prep: fixed-point scale per query -------------------------------------
@@ -187,9 +203,9 @@ static_assert(kDocsPerThread == 32 && (1 << kAccPadShift) == kDocsPerThread, "on
 static_assert(kSlots >= kRangeDocs / kSlotPostings, "the longest possible run must fit an empty slot table");
 
 struct ScanTab {
-    float w[kScanTermChunk];  // per run (term slot of the chunk): query weight * fixed-point scale
     unsigned e0[kSlots];      // per slot: first posting, relative to the range's block
-    unsigned cr[kSlots];      // per slot: postings << 8 | run
+    unsigned n[kSlots];       // per slot: postings (a multiple of 4, at most 64; 0 = unused slot)
+    float ws[kSlots];         // per slot: query weight of its run * fixed-point scale
     unsigned long long base;  // first posting of the range's block
     int n_slots;              // slots in use
     int range;                // range - r0
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
     const uint32_t* __restrict__ post, const int32_t* __restrict__ pq_n, const int32_t* __restrict__ pq_idx,
     const float* __restrict__ pq_w, int stride, const float* __restrict__ q_scale,
     const uint8_t* __restrict__ rowmask, int64_t n_docs, int64_t n_groups, int group_docs, int64_t n_ranges,
-    int rpb, float* __restrict__ gmax) {
+    int rpb, const uint32_t* __restrict__ idle_postings, float* __restrict__ gmax) {
     constexpr int K = kScanK, NW = kScanWaves, DPT = kDocsPerThread;
     __shared__ int acc[kAccWords];
     __shared__ ScanTab tab[2];  // T(s) lives in tab[s & 1]
@@ -251,7 +267,9 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
     };
     auto p_build = [&](ScanTab& T) {  // the next step: as many whole runs of the current unit as fit the slot table
         if (g_cur >= G) {
-            if (lane == 0) { T.n_slots = 0; T.range_done = 0; T.end = 1; T.base = 0; }  // base 0: the refill of an empty step still reads valid bytes
+#pragma unroll 1
+            for (int i = lane; i < kSlots; i += 64) T.n[i] = 0u;
+            if (lane == 0) { T.n_slots = 0; T.range_done = 0; T.end = 1; T.base = 0; }
             return;
         }
         const int range = g_cur / n_chunks, chunk = g_cur - range * n_chunks;
@@ -277,12 +295,12 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
             const int t = 4 * lane + j;
             const bool fits = t >= p_pos && t < nt && first + cnt[j] <= (unsigned)kSlots;
             if (fits) {
-                T.w[t] = wc[j];
                 unsigned e = loc[j];
 #pragma unroll 1
                 for (unsigned c = 0; c < cnt[j]; ++c, e += kSlotPostings) {
                     T.e0[first + c] = e;
-                    T.cr[first + c] = (min((unsigned)kSlotPostings, hic[j] - e) << 8) | (unsigned)t;
+                    T.n[first + c] = min((unsigned)kSlotPostings, hic[j] - e);
+                    T.ws[first + c] = wc[j];
                 }
                 ++taken;
                 used = first + cnt[j];
@@ -295,6 +313,8 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
             taken += __shfl_xor(taken, off);
             used = max(used, (unsigned)__shfl_xor((int)used, off));
         }
+#pragma unroll 1
+        for (int i = (int)used + lane; i < kSlots; i += 64) T.n[i] = 0u;  // unused slots fetch idle postings
         const int p_end = p_pos + taken;
         const bool unit_done = p_end >= nt;
         if (lane == 0) {
@@ -317,11 +337,13 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
 
     // ---- L stage: lane group q = lane / 16 serves slot 4 * item + q with one 16-byte load per lane
     const int sub = lane >> 4, l16 = lane & 15;
+    // Lanes with nothing to fetch (behind the end of a run, unused slots) read 16 bytes of IDLE postings
+    // instead: weight 0, each lane's aimed at an accumulator pad word of its own.  So there is no branch
+    // around the load and no validity test per posting: every lane applies four postings per item.
+    const uint32_t* idle = idle_postings + 4 * lane;
     auto load_item = [&](const ScanTab& T, const uint32_t* pp, int item) -> u32x4_a4 {
         const int slot = 4 * item + sub;
-        const unsigned n = slot < T.n_slots ? T.cr[slot] >> 8 : 0u;
-        // lanes with nothing to fetch read the block's first 16 bytes: no branch around the load
-        const uint32_t* a = (unsigned)(4 * l16) < n ? pp + T.e0[slot] + 4 * l16 : pp;
+        const uint32_t* a = (unsigned)(4 * l16) < T.n[slot] ? pp + T.e0[slot] + 4 * l16 : idle;
 #if defined(HR_ABLATE) && HR_ABLATE == 2  // timing-only build: no posting loads, synthetic postings instead
         const unsigned x = (T.e0[slot] + 4 * l16) * 2654435761u;
         return (u32x4_a4){(x >> 7 & 0x3FFFu) | 0x3C000000u, (x >> 11 & 0x3FFFu) | 0x3C000000u, (x >> 5 & 0x3FFFu) | 0x3C000000u, (x >> 13 & 0x3FFFu) | 0x3C000000u};
@@ -330,18 +352,15 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
 #endif
     };
     auto apply_item = [&](const ScanTab& T, int item, const u32x4_a4& v) {
-        const int slot = 4 * item + sub;
-        const unsigned cr = slot < T.n_slots ? T.cr[slot] : 0u;
-        const int n_valid = (int)(cr >> 8) - 4 * l16;
-        const float wr = T.w[cr & 255u];
+        const float wr = T.ws[4 * item + sub];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t p = v[j];
             const int c = (int)fmaf(posting_weight(p), wr, 1.0f);  // trunc(product + 1): see sparse_query_prep_kernel
 #if defined(HR_ABLATE) && HR_ABLATE == 1  // timing-only build: postings are fetched but not applied
-            if (j < n_valid) asm volatile("" ::"v"(c), "v"(p & 0xFFFFu));
+            asm volatile("" ::"v"(c), "v"(p & 0xFFFFu));
 #else
-            if (j < n_valid) atomicAdd(&acc[p & 0xFFFFu], c);
+            atomicAdd(&acc[p & 0xFFFFu], c);
 #endif
         }
     };
@@ -388,21 +407,27 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         if (range_done) {
             // per-group maxima of the finished range, and zero for the next one: a thread owns DPT consecutive docs
             const int64_t doc0 = range * kRangeDocs + (int64_t)tid * DPT;
-            unsigned alive = 0xFFFFFFFFu;  // filter bits of the thread's docs (bit i = doc0 + i)
+            int* mine = acc + tid * (DPT + 1);
+            int m0 = 0, m1 = 0;  // maxima of docs 0..15 / 16..31 of the thread's slice
             if (rowmask) {
-                alive = 0u;
+                unsigned alive = 0u;  // filter bits of the thread's docs (bit i = doc0 + i)
 #pragma unroll
                 for (int b = 0; b < DPT / 8; ++b)  // docs past the shard have empty accumulators: their bits do not matter
                     alive |= (doc0 + 8 * b < n_docs ? (unsigned)rowmask[(doc0 >> 3) + b] : 0u) << (8 * b);
-            }
-            int* mine = acc + tid * (DPT + 1);
-            int m0 = 0, m1 = 0;  // maxima of docs 0..15 / 16..31 of the thread's slice
 #pragma unroll
-            for (int i = 0; i < DPT; ++i) {
-                int v = mine[i];
-                mine[i] = 0;
-                v = (alive >> i) & 1u ? v : 0;
-                if (i < 16) m0 = max(m0, v); else m1 = max(m1, v);
+                for (int i = 0; i < DPT; ++i) {
+                    int v = mine[i];
+                    mine[i] = 0;
+                    v = (alive >> i) & 1u ? v : 0;
+                    if (i < 16) m0 = max(m0, v); else m1 = max(m1, v);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < DPT; ++i) {
+                    const int v = mine[i];
+                    mine[i] = 0;
+                    if (i < 16) m0 = max(m0, v); else m1 = max(m1, v);
+                }
             }
             if (group_docs == 16) {
                 const int64_t group = range * (kRangeDocs / 16) + tid * (DPT / 16);
