@@ -55,6 +55,19 @@ __host__ __device__ inline int64_t chunk_index(int64_t row, int kchunk, int KT) 
 // global loads in flight across the barrier wants to wait for its own LDS/scalar operations only.
 __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts / broadcasts: six vector instructions and no
+// LDS round trip (each __shfl_up step is a ds_bpermute, ~100 cycles on the critical path of a lone wave).
+__device__ inline unsigned wave_scan_add(unsigned x) {
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1, 3
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ inline unsigned wave_sum(unsigned x) { return (unsigned)__builtin_amdgcn_readlane((int)wave_scan_add(x), 63); }
+
 __device__ inline float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));

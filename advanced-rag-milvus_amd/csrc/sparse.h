@@ -65,12 +65,13 @@ __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int*
 // The scan is only the candidate generator (the refine recomputes from the fp32
 // CSR), so the weight may be rounded; a positive weight never rounds to zero, so
 // "accumulator > 0  <=>  some positive product" still holds.
-// Accumulator slot of local doc d = d + d / 32: the scan's LDS accumulators carry one pad word per
-// 32 docs (conflict-free group-max reads), and storing the padded index here saves the scan two
-// instructions per posting.
+// Accumulator slot of local doc d = d + 2 * (d / 32): the scan's LDS accumulators carry two pad words per
+// 32 docs (a thread's slice of 32 docs then starts 8-byte aligned and a half-wave's slices fall on distinct
+// banks), and storing the padded index here saves the scan two instructions per posting.
 constexpr int kAccPadShift = 5;
-constexpr int kAccWords = kRangeDocs + (kRangeDocs >> kAccPadShift);
-__host__ __device__ inline int acc_slot(int local_doc) { return local_doc + (local_doc >> kAccPadShift); }
+constexpr int kAccSlice = (1 << kAccPadShift) + 2;                 // words per 32-doc slice
+constexpr int kAccWords = (kRangeDocs >> kAccPadShift) * kAccSlice;
+__host__ __device__ inline int acc_slot(int local_doc) { return local_doc + 2 * (local_doc >> kAccPadShift); }
 __device__ inline uint32_t pack_posting(uint16_t local_doc, float w) {
     union { _Float16 h; unsigned short u; } cv;
     cv.h = (_Float16)w;  // round to nearest even
@@ -105,7 +106,7 @@ __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int
 
 // Filler postings behind the last real posting of every run (up to 3): weight 0, aimed at one of the
 // accumulators' pad words, which nobody reads.  cursor = where sparse_fill_kernel stopped.
-__device__ __host__ inline uint32_t filler_posting(unsigned int k) { return (uint32_t)(33u * (k & 511u) + 32u); }
+__device__ __host__ inline uint32_t filler_posting(unsigned int k) { return (uint32_t)(kAccSlice * (k & 511u) + 32u); }
 __global__ void sparse_pad_kernel(const unsigned int* __restrict__ rt_off, const unsigned int* __restrict__ cursor,
                                   int64_t V1, int64_t n_ranges, const int64_t* __restrict__ range_base,
                                   uint32_t* __restrict__ post) {
@@ -199,7 +200,7 @@ constexpr int kScanK = 8;                               // items a wave keeps in
 constexpr int kSlotPostings = 64;                       // postings per slot (16 lanes x 4)
 constexpr int kSlots = kScanK * kScanWaves * 4;         // slots per step = everything one round of loads covers
 constexpr int kDocsPerThread = kRangeDocs / kScanThreads;  // consecutive docs a thread reduces in the group-max pass
-static_assert(kDocsPerThread == 32 && (1 << kAccPadShift) == kDocsPerThread, "one pad word per thread slice");
+static_assert(kDocsPerThread == 32 && (1 << kAccPadShift) == kDocsPerThread, "one padded slice per thread");
 static_assert(kSlots >= kRangeDocs / kSlotPostings, "the longest possible run must fit an empty slot table");
 
 struct ScanTab {
@@ -281,15 +282,10 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
             cnt[j] = (t >= p_pos && t < nt) ? (hic[j] - loc[j] + kSlotPostings - 1) / kSlotPostings : 0u;
             mine += cnt[j];
         }
-        unsigned incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned y = __shfl_up(incl, off);
-            if (lane >= off) incl += y;
-        }
+        const unsigned incl = wave_scan_add(mine);
         unsigned first = incl - mine;
-        int taken = 0;           // term slots of this lane that go into the step
-        unsigned used = 0;       // slots in use after this lane's runs
+        unsigned taken = 0;  // term slots of this lane that go into the step
+        unsigned used = 0;   // slots this lane's runs add to the step
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = 4 * lane + j;
@@ -303,19 +299,16 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
                     T.ws[first + c] = wc[j];
                 }
                 ++taken;
-                used = first + cnt[j];
+                used += cnt[j];
             }
             first += cnt[j];
         }
-        // the prefix is monotone, so the runs that fit are exactly the first ones
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            taken += __shfl_xor(taken, off);
-            used = max(used, (unsigned)__shfl_xor((int)used, off));
-        }
+        // the prefix is monotone, so the runs that fit are exactly the first ones: their slot counts simply add up
+        taken = wave_sum(taken);
+        used = wave_sum(used);
 #pragma unroll 1
         for (int i = (int)used + lane; i < kSlots; i += 64) T.n[i] = 0u;  // unused slots fetch idle postings
-        const int p_end = p_pos + taken;
+        const int p_end = p_pos + (int)taken;
         const bool unit_done = p_end >= nt;
         if (lane == 0) {
             T.n_slots = (int)used;
@@ -407,27 +400,28 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         if (range_done) {
             // per-group maxima of the finished range, and zero for the next one: a thread owns DPT consecutive docs
             const int64_t doc0 = range * kRangeDocs + (int64_t)tid * DPT;
-            int* mine = acc + tid * (DPT + 1);
-            int m0 = 0, m1 = 0;  // maxima of docs 0..15 / 16..31 of the thread's slice
+            // one LDS exchange per pair of docs reads the accumulators and leaves zeros behind
+            unsigned long long* mine = reinterpret_cast<unsigned long long*>(acc + tid * kAccSlice);
+            int v[DPT];
+#pragma unroll
+            for (int i = 0; i < DPT / 2; ++i) {
+                const unsigned long long x = __hip_atomic_exchange(mine + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                v[2 * i] = (int)(unsigned)x;
+                v[2 * i + 1] = (int)(unsigned)(x >> 32);
+            }
             if (rowmask) {
                 unsigned alive = 0u;  // filter bits of the thread's docs (bit i = doc0 + i)
 #pragma unroll
                 for (int b = 0; b < DPT / 8; ++b)  // docs past the shard have empty accumulators: their bits do not matter
                     alive |= (doc0 + 8 * b < n_docs ? (unsigned)rowmask[(doc0 >> 3) + b] : 0u) << (8 * b);
 #pragma unroll
-                for (int i = 0; i < DPT; ++i) {
-                    int v = mine[i];
-                    mine[i] = 0;
-                    v = (alive >> i) & 1u ? v : 0;
-                    if (i < 16) m0 = max(m0, v); else m1 = max(m1, v);
-                }
-            } else {
+                for (int i = 0; i < DPT; ++i) v[i] = (alive >> i) & 1u ? v[i] : 0;
+            }
+            int m0 = 0, m1 = 0;  // maxima of docs 0..15 / 16..31 of the thread's slice
 #pragma unroll
-                for (int i = 0; i < DPT; ++i) {
-                    const int v = mine[i];
-                    mine[i] = 0;
-                    if (i < 16) m0 = max(m0, v); else m1 = max(m1, v);
-                }
+            for (int i = 0; i < 16; ++i) {
+                m0 = max(m0, v[i]);
+                m1 = max(m1, v[16 + i]);
             }
             if (group_docs == 16) {
                 const int64_t group = range * (kRangeDocs / 16) + tid * (DPT / 16);
