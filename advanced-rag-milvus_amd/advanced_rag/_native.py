@@ -232,6 +232,16 @@ class ShardHandle:
         return int(self._lib.hr_dense_scan_bytes(self._h))
 
     # -- search, host buffers
+    @staticmethod
+    def _mask(rowmask, n_rows: int):
+        """The library copies (n_rows + 7) // 8 bytes of a row mask: a shorter buffer would be over-read."""
+        if rowmask is None:
+            return None
+        m = np.ascontiguousarray(rowmask, dtype=np.uint8)
+        if m.size < (n_rows + 7) // 8:
+            raise ValueError(f"row mask has {m.size} bytes, the collection's {n_rows} rows need {(n_rows + 7) // 8}")
+        return m
+
     def search_dense(self, q: np.ndarray, k: int, rowmask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
         q = np.ascontiguousarray(np.atleast_2d(q), dtype=np.float32)
         if q.shape[1] != self.dim:
@@ -239,7 +249,7 @@ class ShardHandle:
         B = q.shape[0]
         ids = np.empty((B, k), dtype=np.int64)
         sc = np.empty((B, k), dtype=np.float32)
-        m = None if rowmask is None else np.ascontiguousarray(rowmask, dtype=np.uint8)
+        m = self._mask(rowmask, self.num_rows)
         self._check(self._lib.hr_search_dense(self._h, _vp(q), B, k, _vp(m), _vp(ids), _vp(sc)))
         return ids, sc
 
@@ -255,7 +265,7 @@ class ShardHandle:
         val = np.ascontiguousarray(val, dtype=np.float32)
         ids = np.empty((B, k), dtype=np.int64)
         sc = np.empty((B, k), dtype=np.float32)
-        m = None if rowmask is None else np.ascontiguousarray(rowmask, dtype=np.uint8)
+        m = self._mask(rowmask, self.num_sparse_rows)
         self._check(self._lib.hr_search_sparse(self._h, _vp(indptr), _vp(idx), _vp(val), B, k, float(drop_ratio),
                                                _vp(m), _vp(ids), _vp(sc)))
         return ids, sc

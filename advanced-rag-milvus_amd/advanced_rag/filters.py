@@ -11,6 +11,7 @@ the kernels as a packed bitmask (bit r%8 of byte r/8).
 """
 from __future__ import annotations
 
+import re
 from typing import Any, Dict, List, Tuple
 
 import numpy as np
@@ -61,17 +62,18 @@ def _unquote(tok: str) -> str:
     return "".join(out)
 
 
+_TERM = re.compile(r"^\s*([A-Za-z_]\w*)\s*(>=|<=|==|!=|>|<)\s*(.+?)\s*$", re.S)
+
+
 def parse(expr: str) -> List[Tuple[str, str, Any]]:
-    """-> [(field, op, python value)]"""
+    """-> [(field, op, python value)].  The operator is the one right after the field name: a quoted value
+    may itself contain ' >= ', ' and ' or escaped quotes (doc_id == "a >= b")."""
     parsed = []
     for term in _split_terms(expr):
-        for op in _OPS:
-            pos = term.find(f" {op} ")
-            if pos > 0:
-                field, raw = term[:pos].strip(), term[pos + len(op) + 2:].strip()
-                break
-        else:
+        m = _TERM.match(term)
+        if m is None:
             raise ValueError(f"cannot parse filter term: {term!r}")
+        field, op, raw = m.group(1), m.group(2), m.group(3)
         if raw.startswith('"') and raw.endswith('"') and len(raw) >= 2:
             value: Any = _unquote(raw)
         elif raw in ("True", "true"):

@@ -4,8 +4,11 @@
 (reference src/advanced_rag/indexing.py:80-713) with the Milvus server replaced
 by libhbmrag: the three collections ("semantic_index" dense/COSINE,
 "sparse_index" sparse/IP, "domain_index" dense/COSINE; indexing.py:143-180)
-live in the HBM of one GPU as a tiled fp16/fp32 matrix plus doc-range postings,
-and `search` runs the HIP kernels instead of an RPC (indexing.py:503-525).
+live in HBM as a tiled fp16/fp32 matrix plus doc-range postings — on one GPU, or
+spread over several (`devices=[0, 1, ...]`: one shard handle per device, searched in
+parallel and merged, the counterpart of the reference's server-side `num_shards`,
+indexing.py:234-239) — and `search` runs the HIP kernels instead of an RPC
+(indexing.py:503-525).
 Host and port are accepted and ignored.  Payload columns (content, ids, scalar
 fields of the schema, indexing.py:191-225) stay on the host, keyed by row.
 
@@ -33,6 +36,7 @@ import numpy as np
 from . import filters as _filters
 from .constants import IndexingConstants
 from .embedding_cache import get_semantic_cache
+from .shards import ShardSet
 
 logger = logging.getLogger(__name__)
 
@@ -67,8 +71,8 @@ class IndexConfig:
 
 
 class ShardCollection:
-    """What `manager.collections[name]` holds: a named view of one shard handle
-    with the handful of Collection methods the reference calls
+    """What `manager.collections[name]` holds: a named view of one ShardSet (the
+    collection's shard handles, one per device) with the handful of Collection methods the reference calls
     (num_entities / flush / load / release / delete, indexing.py:259, :430, :683-701)."""
 
     def __init__(self, manager: "MilvusIndexManager", name: str, kind: str, handle, dim: int, metric: str):
@@ -103,23 +107,27 @@ class ShardCollection:
 class MilvusIndexManager:
     def __init__(self, host: str = "localhost", port: int = 19530, enable_sharding: bool = True, num_shards: int = 4,
                  semantic_dim: int = 1536, sparse_dim: int = 10000, domain_dim: int = 768, connect: bool = True,
-                 *, dtype: str = "float16", device: int = 0, enable_domain: bool = True,
-                 device_embedding_cache: int = 0):
+                 *, dtype: str = "float16", device: int = 0, devices: Optional[Sequence[int]] = None,
+                 enable_domain: bool = True, device_embedding_cache: int = 0):
         self.host, self.port = host, port
         self.enable_sharding, self.num_shards = enable_sharding, num_shards
         self.semantic_dim, self.sparse_dim, self.domain_dim = semantic_dim, sparse_dim, domain_dim
-        self.dtype, self.device, self.enable_domain = dtype, device, enable_domain
+        # devices = GPU of every shard (a device may be named more than once); default: one shard on `device`
+        self.devices = [int(d) for d in devices] if devices else [int(device)]
+        self.dtype, self.device, self.enable_domain = dtype, self.devices[0], enable_domain
         self.collections: Dict[str, ShardCollection] = {}
         self.embedding_generator = None
         self.embedding_executor = ThreadPoolExecutor(max_workers=IndexingConstants.THREAD_POOL_WORKERS,
                                                      thread_name_prefix="embedding-")
-        self._main = None      # ShardHandle: semantic + sparse
-        self._domain = None    # ShardHandle: domain
+        self._main = None      # ShardSet: semantic + sparse
+        self._domain = None    # ShardSet: domain
         self._cols: Dict[str, list] = {k: [] for k in ("id", "doc_id", "content", "chunk_index", "token_count",
                                                        "entropy", "redundancy", "domain_density", "timestamp",
                                                        "metadata_json")}
         self._np_cols: Optional[Dict[str, np.ndarray]] = None
         self._deleted: Optional[np.ndarray] = None
+        self._mask_cache: Dict[Any, Optional[np.ndarray]] = {}   # (expr, rows, delete epoch) -> boolean row filter
+        self._delete_epoch = 0
         self._synthetic_rows = 0   # rows whose payload is derived from the row number (bulk/benchmark ingest)
         # "embedding cache -> device-resident tensor": with device_embedding_cache=N > 0 the semantic QUERY
         # embeddings are kept in one [N, dim] HBM tensor; a hit hands the search kernel a device pointer
@@ -140,17 +148,40 @@ class MilvusIndexManager:
         nat = self._native
         store = nat.HR_F16 if self.dtype in ("float16", "fp16", "f16") else nat.HR_F32
         sparse_on = os.getenv("ENABLE_SPARSE", "1") == "1"
-        self._main = nat.ShardHandle(self.semantic_dim, store, nat.HR_METRIC_COSINE,
-                                     self.sparse_dim if sparse_on else 0, self.device)
+        self._main = ShardSet([nat.ShardHandle(self.semantic_dim, store, nat.HR_METRIC_COSINE,
+                                               self.sparse_dim if sparse_on else 0, d) for d in self.devices])
         self.collections["semantic_index"] = ShardCollection(self, "semantic_index", "dense", self._main,
                                                              self.semantic_dim, "COSINE")
         if sparse_on:
             self.collections["sparse_index"] = ShardCollection(self, "sparse_index", "sparse", self._main,
                                                                self.sparse_dim, "IP")
         if self.enable_domain:
-            self._domain = nat.ShardHandle(self.domain_dim, store, nat.HR_METRIC_COSINE, 0, self.device)
+            self._domain = ShardSet([nat.ShardHandle(self.domain_dim, store, nat.HR_METRIC_COSINE, 0, d)
+                                     for d in self.devices])
             self.collections["domain_index"] = ShardCollection(self, "domain_index", "dense", self._domain,
                                                                self.domain_dim, "COSINE")
+
+    def attach_shards(self, handles, rows_of=None, synthetic_rows: int = 0):
+        """Adopt already-built shard handles as the semantic (+ sparse) collection — e.g. the shard a benchmark has
+        just filled.  rows_of[s] = global row of every local row of shard s (default: shard s follows shard s-1)."""
+        if not hasattr(self, "_native"):
+            self._connect()
+        handles = list(handles)
+        if rows_of is None:
+            rows_of, base = [], 0
+            for h in handles:
+                rows_of.append(np.arange(base, base + h.num_rows, dtype=np.int64))
+                base += h.num_rows
+        self._main = ShardSet(handles)
+        self._main.rows_of = [np.asarray(r, dtype=np.int64) for r in rows_of]
+        self._main._n = int(sum(len(r) for r in rows_of))
+        self.devices = [h.device for h in handles]
+        self.collections["semantic_index"] = ShardCollection(self, "semantic_index", "dense", self._main,
+                                                             self.semantic_dim, "COSINE")
+        if handles[0].sparse_dim:
+            self.collections["sparse_index"] = ShardCollection(self, "sparse_index", "sparse", self._main,
+                                                               self.sparse_dim, "IP")
+        self._synthetic_rows = int(synthetic_rows)
 
     # ------------------------------------------------------------------ host columns
     def _columns(self) -> Dict[str, np.ndarray]:
@@ -177,18 +208,28 @@ class MilvusIndexManager:
         return f"doc{row // 10}::{row % 10}::{row:08x}"
 
     def _row_mask(self, expr: Optional[str]) -> Optional[np.ndarray]:
+        """Boolean filter over global rows for a filter expression plus the tombstones, or None for "all rows".
+        Evaluating an expression is a pass over every payload row: the result is kept per (expression, row count,
+        tombstone epoch) so that repeated requests with the same filter pay for it once."""
         if self._synthetic_rows:
             if expr:
                 raise ValueError("filter expressions need payload columns; this shard was bulk-ingested without them")
             return None
         n = self.num_rows
+        key = (expr, n, self._delete_epoch)
+        if key in self._mask_cache:
+            return self._mask_cache[key]
         keep = None
         if expr:
             keep = _filters.evaluate(expr, self._columns(), n)
         if self._deleted is not None and self._deleted[:n].any():
-            alive = ~self._deleted[:n]
+            alive = np.ones(n, dtype=bool)
+            alive[:self._deleted.shape[0]] = ~self._deleted[:n]
             keep = alive if keep is None else (keep & alive)
-        return None if keep is None else _filters.pack(keep)
+        if len(self._mask_cache) >= 64:
+            self._mask_cache.pop(next(iter(self._mask_cache)))
+        self._mask_cache[key] = keep
+        return keep
 
     def _tombstone(self, expr: str):
         n = self.num_rows
@@ -199,6 +240,7 @@ class MilvusIndexManager:
                 grown[:self._deleted.shape[0]] = self._deleted
             self._deleted = grown
         self._deleted[:n] |= hit
+        self._delete_epoch += 1
 
     # ------------------------------------------------------------------ ingest
     async def index_chunks(self, chunks: List["Chunk"], domain: Optional[str] = None) -> Dict[str, Any]:
@@ -218,7 +260,7 @@ class MilvusIndexManager:
                 sp = None
                 if use_sparse:
                     try:
-                        sp = self._as_sparse_payload(await self._generate_sparse_embedding(chunk.text, role="document"))
+                        sp = self._clean_sparse_payload(await self._generate_sparse_embedding(chunk.text, role="document"))
                         n_sparse_ok += 1
                     except Exception as e:
                         summary["errors"].append({"chunk_id": chunk.metadata.chunk_id,
@@ -246,39 +288,50 @@ class MilvusIndexManager:
         try:
             if "semantic_index" not in self.collections:
                 raise KeyError("semantic_index")
-            await asyncio.to_thread(self._main.add_dense, np.stack(rows_dense))
+            sparse_csr = None
+            if use_sparse:
+                sparse_csr = (np.asarray(sp_ptr, np.int64), np.concatenate(sp_idx) if sp_idx else np.zeros(0, np.int32),
+                              np.concatenate(sp_val) if sp_val else np.zeros(0, np.float32))
+            # dense rows, sparse rows and payload columns of a chunk share one row number: the three are appended
+            # together, and whatever fails afterwards is padded rather than left short
+            _, _, sparse_err = await asyncio.to_thread(self._main.add, np.stack(rows_dense), sparse_csr)
+            self._append_payload(kept)
             summary["indexed_semantic"] = len(kept)
             if use_sparse:
-                try:
-                    await asyncio.to_thread(self._main.add_sparse, np.asarray(sp_ptr, np.int64),
-                                            np.concatenate(sp_idx) if sp_idx else np.zeros(0, np.int32),
-                                            np.concatenate(sp_val) if sp_val else np.zeros(0, np.float32))
+                if sparse_err is None:
                     summary["indexed_sparse"] = n_sparse_ok
-                except Exception as e:
-                    logger.warning("Sparse insert failed; continuing without sparse index: %s", e)
-                    summary["errors"].append({"insert_sparse_error": str(e)})
-            if rows_domain:
-                await asyncio.to_thread(self._domain.add_dense, np.stack(rows_domain))
-                summary["indexed_domain"] = len(rows_domain)
-            for chunk in kept:
-                m = chunk.metadata
-                c = self._cols
-                c["id"].append(m.chunk_id)
-                c["doc_id"].append(str(m.doc_id))
-                c["content"].append(chunk.text[:65535])
-                c["chunk_index"].append(int(m.chunk_index))
-                c["token_count"].append(int(m.token_count))
-                c["entropy"].append(_f32(m.entropy))
-                c["redundancy"].append(_f32(m.redundancy))
-                c["domain_density"].append(_f32(m.domain_density))
-                c["timestamp"].append(str(m.timestamp))
-                c["metadata_json"].append(str(m.to_dict())[:10000])
-            self._np_cols = None
+                else:
+                    logger.warning("Sparse insert failed; continuing without sparse index: %s", sparse_err)
+                    summary["errors"].append({"insert_sparse_error": str(sparse_err)})
+            if "domain_index" in self.collections:
+                try:
+                    await asyncio.to_thread(self._domain.add, np.stack(rows_domain))
+                    summary["indexed_domain"] = len(rows_domain)
+                except Exception as e:  # zero rows never match (cosine 0): the domain collection stays row-aligned
+                    await asyncio.to_thread(self._domain.add, np.zeros((len(kept), self.domain_dim), np.float32))
+                    summary["errors"].append({"insert_domain_error": str(e)})
             for coll in {id(c.handle): c for c in self.collections.values()}.values():
                 await asyncio.to_thread(coll.flush)
         except Exception as e:
             summary["errors"].append({"insert_error": str(e)})
         return summary
+
+    def _append_payload(self, chunks):
+        c = self._cols
+        for chunk in chunks:
+            m = chunk.metadata
+            c["id"].append(m.chunk_id)
+            c["doc_id"].append(str(m.doc_id))
+            c["content"].append(chunk.text[:65535])
+            c["chunk_index"].append(int(m.chunk_index))
+            c["token_count"].append(int(m.token_count))
+            c["entropy"].append(_f32(m.entropy))
+            c["redundancy"].append(_f32(m.redundancy))
+            c["domain_density"].append(_f32(m.domain_density))
+            c["timestamp"].append(str(m.timestamp))
+            c["metadata_json"].append(str(m.to_dict())[:10000])
+        self._np_cols = None
+        self._mask_cache.clear()
 
     def add_rows(self, dense: np.ndarray, sparse_csr=None, ids: Optional[Sequence[str]] = None,
                  contents: Optional[Sequence[str]] = None, **scalar_columns):
@@ -288,9 +341,7 @@ class MilvusIndexManager:
             raise ValueError("shard is in synthetic-payload mode; use add_rows_synthetic")
         n = dense.shape[0]
         base = self.num_rows
-        self._main.add_dense(dense)
-        if sparse_csr is not None and "sparse_index" in self.collections:
-            self._main.add_sparse(*sparse_csr)
+        _, _, sparse_err = self._main.add(dense, sparse_csr if "sparse_index" in self.collections else None)
         c = self._cols
         c["id"].extend(ids if ids is not None else [f"doc{(base + r) // 10}::{(base + r) % 10}::{base + r:08x}"
                                                     for r in range(n)])
@@ -303,16 +354,19 @@ class MilvusIndexManager:
             vals = list(given) if given is not None else [fn(r) for r in range(n)]
             c[name].extend([_f32(v) for v in vals] if name in _FLOAT_FIELDS else vals)
         self._np_cols = None
+        self._mask_cache.clear()
+        if sparse_err is not None:  # the rows are in (with empty sparse rows); the caller still hears about it
+            raise sparse_err
 
     def add_rows_synthetic(self, dense: np.ndarray, sparse_csr=None):
         """Bulk ingest without host payload columns: ids/metadata are derived from the row
         number on demand (10M-row benchmarks would otherwise hold GBs of Python strings)."""
         if self._cols["id"]:
             raise ValueError("shard already holds payload columns")
-        self._main.add_dense(dense)
-        if sparse_csr is not None and "sparse_index" in self.collections:
-            self._main.add_sparse(*sparse_csr)
+        _, _, sparse_err = self._main.add(dense, sparse_csr if "sparse_index" in self.collections else None)
         self._synthetic_rows += dense.shape[0]
+        if sparse_err is not None:
+            raise sparse_err
 
     def finalize(self):
         for coll in {id(c.handle): c for c in self.collections.values()}.values():
@@ -323,39 +377,42 @@ class MilvusIndexManager:
         """Write the shard(s) and the host payload columns to `directory` (resume without re-embedding)."""
         os.makedirs(directory, exist_ok=True)
         self.finalize()
-        self._main.save(os.path.join(directory, "main.hbmrag"))
+        self._main.save(lambda s: os.path.join(directory, f"main.{s}.hbmrag"))
         if self._domain is not None:
-            self._domain.save(os.path.join(directory, "domain.hbmrag"))
+            self._domain.save(lambda s: os.path.join(directory, f"domain.{s}.hbmrag"))
         cols = {k: np.asarray(v, dtype=str if k in ("id", "doc_id", "content", "timestamp", "metadata_json") else None)
                 for k, v in self._cols.items()}
         deleted = self._deleted if self._deleted is not None else np.zeros(0, dtype=bool)
+        maps = {f"rows_main_{s}": r for s, r in enumerate(self._main.row_maps())}
+        if self._domain is not None:
+            maps.update({f"rows_domain_{s}": r for s, r in enumerate(self._domain.row_maps())})
         np.savez(os.path.join(directory, "payload.npz"), synthetic_rows=np.int64(self._synthetic_rows), deleted=deleted,
-                 **{f"col_{k}": v for k, v in cols.items()})
+                 n_shards=np.int64(self._main.n_shards), **maps, **{f"col_{k}": v for k, v in cols.items()})
 
     def load_snapshot(self, directory: str) -> None:
-        """Replace this manager's (empty) collections with the ones saved by `save_snapshot`."""
+        """Replace this manager's (empty) collections with the ones saved by `save_snapshot`; the manager must have
+        been created with as many devices as the snapshot has shards."""
         nat = self._native
         store = nat.HR_F16 if self.dtype in ("float16", "fp16", "f16") else nat.HR_F32
         sparse_on = "sparse_index" in self.collections
-        main = nat.ShardHandle.load(os.path.join(directory, "main.hbmrag"), self.semantic_dim, store,
-                                    nat.HR_METRIC_COSINE, self.sparse_dim if sparse_on else 0, self.device)
-        if self._main is not None:
-            self._main.close()
-        self._main = main
-        for name in ("semantic_index", "sparse_index"):
-            if name in self.collections:
-                self.collections[name].handle = main
-        dom_path = os.path.join(directory, "domain.hbmrag")
-        if self._domain is not None and os.path.exists(dom_path):
-            self._domain.close()
-            self._domain = nat.ShardHandle.load(dom_path, self.domain_dim, store, nat.HR_METRIC_COSINE, 0, self.device)
-            self.collections["domain_index"].handle = self._domain
         with np.load(os.path.join(directory, "payload.npz"), allow_pickle=False) as z:
+            n_shards = int(z["n_shards"])
+            if n_shards != len(self.devices):
+                raise ValueError(f"snapshot has {n_shards} shards, this manager was created with {len(self.devices)} devices")
+            main = [nat.ShardHandle.load(os.path.join(directory, f"main.{s}.hbmrag"), self.semantic_dim, store,
+                                         nat.HR_METRIC_COSINE, self.sparse_dim if sparse_on else 0, d)
+                    for s, d in enumerate(self.devices)]
+            self._main.adopt(main, [z[f"rows_main_{s}"] for s in range(n_shards)])
+            if self._domain is not None and os.path.exists(os.path.join(directory, "domain.0.hbmrag")):
+                dom = [nat.ShardHandle.load(os.path.join(directory, f"domain.{s}.hbmrag"), self.domain_dim, store,
+                                            nat.HR_METRIC_COSINE, 0, d) for s, d in enumerate(self.devices)]
+                self._domain.adopt(dom, [z[f"rows_domain_{s}"] for s in range(n_shards)])
             self._synthetic_rows = int(z["synthetic_rows"])
             self._deleted = z["deleted"].copy() if z["deleted"].size else None
             for k in self._cols:
                 self._cols[k] = z[f"col_{k}"].tolist()
         self._np_cols = None
+        self._mask_cache.clear()
 
     # ------------------------------------------------------------------ search
     @staticmethod
@@ -372,6 +429,24 @@ class MilvusIndexManager:
             raise ValueError("sparse indices/values length mismatch")
         order = np.argsort(idx, kind="stable")
         return idx[order], val[order]
+
+    def _clean_sparse_payload(self, emb):
+        """A DOCUMENT's sparse payload, made acceptable to the shard or rejected here, chunk by chunk — a whole batch
+        must not fail later because of one row: indices in range, values finite and within the fp16 posting range,
+        duplicate indices merged by summing (what scipy's CSR arithmetic does with the reference's payload)."""
+        idx, val = self._as_sparse_payload(emb)
+        if idx.size:
+            if idx[0] < 0 or idx[-1] >= self.sparse_dim:
+                raise ValueError(f"sparse index out of range [0, {self.sparse_dim})")
+            if not np.isfinite(val).all():
+                raise ValueError("non-finite sparse value")
+            if (idx[1:] == idx[:-1]).any():
+                uniq, start = np.unique(idx, return_index=True)
+                val = np.add.reduceat(val.astype(np.float64), start).astype(np.float32)
+                idx = uniq.astype(np.int32)
+            if np.abs(val).max() > 60000.0:
+                raise ValueError("sparse weight exceeds the fp16 posting range (|w| <= 60000)")
+        return idx, val
 
     def _format_hits(self, ids: np.ndarray, scores: np.ndarray) -> List[Dict[str, Any]]:
         c = self._cols
@@ -405,8 +480,9 @@ class MilvusIndexManager:
             idx, val = self._as_sparse_payload(query_embedding)
             drop = float((params.get("params") or {}).get("drop_ratio_search", 0.0))
             ids, sc = coll.handle.search_sparse([(idx, val)], top_k, drop, mask)
-        elif hasattr(query_embedding, "is_cuda") and query_embedding.is_cuda and mask is None:
-            ids, sc = self._search_dense_device(coll.handle, query_embedding, top_k)
+        elif (hasattr(query_embedding, "is_cuda") and query_embedding.is_cuda and mask is None
+              and coll.handle.n_shards == 1):
+            ids, sc = self._search_dense_device(coll.handle.first, query_embedding, top_k)
         else:
             if hasattr(query_embedding, "detach"):
                 query_embedding = query_embedding.detach().cpu().numpy()
@@ -455,7 +531,7 @@ class MilvusIndexManager:
                 row_to_id.setdefault(int(r), i)
         lists = [np.asarray(r, dtype=np.int64) for r in row_lists] + [np.zeros(0, np.int64)] * (3 - len(row_lists))
         w = list(weights) + [0.0] * (3 - len(weights))
-        rows, scores, methods = self._main.fuse_rrf(lists[0], lists[1], lists[2], w[0], w[1], w[2], rrf_k)
+        rows, scores, methods = self._main.first.fuse_rrf(lists[0], lists[1], lists[2], w[0], w[1], w[2], rrf_k)
         return [(row_to_id[int(r)], float(s), [b for b in range(3) if (int(m) >> b) & 1])
                 for r, s, m in zip(rows, scores, methods)]
 

@@ -406,13 +406,7 @@ def measure_latency(h, Q, SQ, args, use_sparse):
     from advanced_rag.retrieval import HybridRetriever, RetrievalConfig
 
     mgr = MilvusIndexManager(semantic_dim=args.dim, sparse_dim=SPARSE_DIM, connect=False)
-    mgr._connect()
-    from advanced_rag.indexing import ShardCollection
-    mgr._main = h
-    mgr.collections["semantic_index"] = ShardCollection(mgr, "semantic_index", "dense", h, args.dim, "COSINE")
-    if use_sparse:
-        mgr.collections["sparse_index"] = ShardCollection(mgr, "sparse_index", "sparse", h, SPARSE_DIM, "IP")
-    mgr._synthetic_rows = h.num_rows
+    mgr.attach_shards([h], synthetic_rows=h.num_rows)
     flatQ = Q.reshape(-1, args.dim)
     flatS = [s for batch in SQ for s in batch]
 

@@ -32,10 +32,8 @@ def t(fn, n=30):
 
 print("host-form dense  B=1 k=40: %.3f ms" % t(lambda: h.search_dense(Q[:1], 40)))
 print("host-form sparse B=1 k=40: %.3f ms" % t(lambda: h.search_sparse(SQ[:1], 40, 0.2)))
-mgr = MilvusIndexManager(semantic_dim=D, sparse_dim=SPARSE_DIM, connect=False); mgr._connect(); mgr._main = h
-mgr.collections["semantic_index"] = ShardCollection(mgr, "semantic_index", "dense", h, D, "COSINE")
-mgr.collections["sparse_index"] = ShardCollection(mgr, "sparse_index", "sparse", h, SPARSE_DIM, "IP")
-mgr._synthetic_rows = h.num_rows
+mgr = MilvusIndexManager(semantic_dim=D, sparse_dim=SPARSE_DIM, connect=False)
+mgr.attach_shards([h], synthetic_rows=h.num_rows)
 class Gen:
     def encode_semantic(self, text): return Q[int(text[1:])]
     def encode_sparse(self, text):
