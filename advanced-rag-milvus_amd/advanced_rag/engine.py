@@ -66,7 +66,9 @@ def pack_sparse_queries(queries: Sequence[Tuple[Sequence[int], Sequence[float]]]
 @dataclass(frozen=True)
 class ListPack:
     """Byte layout of one rank's slot in the all-gather buffer: the ids of every
-    modality ([n_mod][B][kp] int64) followed by their scores ([n_mod][B][kp] fp32).
+    modality ([n_mod][B][kp] int64), their scores ([n_mod][B][kp] fp32), then the per-list
+    "proven exact" flags ([n_mod][B] int32) — so that after the ONE exchange every rank also knows
+    which lists some rank could not prove, and all ranks take the same repair decision.
     Backend-agnostic (torch uint8 tensors on any device) so the gloo CPU tests
     exercise exactly the offsets and strides the HIP merge kernel is given."""
     n_mod: int
@@ -78,15 +80,29 @@ class ListPack:
         return self.n_mod * self.B * self.kp * 8
 
     @property
+    def score_bytes(self) -> int:
+        return self.n_mod * self.B * self.kp * 4
+
+    @property
     def nbytes(self) -> int:
-        return self.id_bytes + self.n_mod * self.B * self.kp * 4
+        raw = self.id_bytes + self.score_bytes + self.n_mod * self.B * 4
+        return -(-raw // 8) * 8  # slots stay 8-byte aligned inside the gathered buffer
 
     def views(self, pack):
         """(ids int64 [n_mod,B,kp], scores float32 [n_mod,B,kp]) views of a 1-D uint8 tensor."""
         import torch
         ids = pack[: self.id_bytes].view(torch.int64).view(self.n_mod, self.B, self.kp)
-        scores = pack[self.id_bytes: self.nbytes].view(torch.float32).view(self.n_mod, self.B, self.kp)
+        scores = pack[self.id_bytes: self.id_bytes + self.score_bytes].view(torch.float32).view(self.n_mod, self.B, self.kp)
         return ids, scores
+
+    def flags_view(self, pack):
+        """int32 [n_mod, B] view of the flags of one slot (1-D uint8 tensor) or of every slot ([world, nbytes])."""
+        import torch
+        lo = self.id_bytes + self.score_bytes
+        hi = lo + self.n_mod * self.B * 4
+        if pack.dim() == 1:
+            return pack[lo:hi].view(torch.int32).view(self.n_mod, self.B)
+        return pack[:, lo:hi].contiguous().view(torch.int32).view(pack.shape[0], self.n_mod, self.B)
 
     def merge_args(self, modality: int):
         """(score byte offset, id byte offset, score stride [floats], id stride [int64s]) of one
@@ -133,7 +149,7 @@ class HybridSearchEngine:
         self.torch = torch
         self.h = handle
         # optional third modality (reference _search_domain, retrieval.py:397-419): a second dense shard over the same
-        # rows searched with k = top_k (not 2k) and fused with weight 0.2; single-shard engines only
+        # rows (sharded the same way when the corpus is), searched with k = top_k (not 2k) and fused with weight 0.2
         self.hd = domain_handle
         self.cfg = config or EngineConfig()
         self.group = process_group
@@ -152,20 +168,23 @@ class HybridSearchEngine:
 
     # ------------------------------------------------------------------ buffers
     def _buffers(self, B: int) -> dict:
+        """Per-batch-size buffers.  Lists live in ONE packed tensor (the rank's slot of the all-gather): modality 0 =
+        dense, 1 = sparse (if used), last = domain (if the engine has a domain shard; its lists hold top_k entries in
+        kp-wide rows, -1 padded)."""
         b = self._bufs.get(B)
         if b is not None:
             return b
         t, dev, cfg = self.torch, self.device, self.cfg
         kp = 2 * cfg.top_k
-        n_mod = 2 if cfg.use_sparse else 1
+        n_main = 2 if cfg.use_sparse else 1
+        n_mod = n_main + (1 if self.hd is not None else 0)
         layout = ListPack(n_mod, B, kp)
         pack = t.zeros(layout.nbytes, dtype=t.uint8, device=dev)
         ids_v, scores_v = layout.views(pack)
+        ids_v.fill_(-1)
         b = {
-            "kp": kp, "n_mod": n_mod, "pack": pack, "layout": layout,
-            "ids": ids_v,
-            "scores": scores_v,
-            "flags": t.zeros((n_mod, B), dtype=t.int32, device=dev),
+            "kp": kp, "n_mod": n_mod, "n_main": n_main, "pack": pack, "layout": layout,
+            "ids": ids_v, "scores": scores_v, "flags": layout.flags_view(pack),
             "fused_ids": t.empty((B, cfg.top_k), dtype=t.int64, device=dev),
             "fused_scores": t.empty((B, cfg.top_k), dtype=t.float64, device=dev),
             "fused_methods": t.empty((B, cfg.top_k), dtype=t.int32, device=dev),
@@ -173,17 +192,39 @@ class HybridSearchEngine:
             "rr_ids": t.empty((B, cfg.rerank_top_k), dtype=t.int64, device=dev),
             "rr_scores": t.empty((B, cfg.rerank_top_k), dtype=t.float64, device=dev),
             "rr_orig": t.empty((B, cfg.rerank_top_k), dtype=t.float64, device=dev),
+            "use_domain": False,
         }
-        if self.hd is not None:
-            b["dom_ids"] = t.empty((B, cfg.top_k), dtype=t.int64, device=dev)
-            b["dom_scores"] = t.empty((B, cfg.top_k), dtype=t.float32, device=dev)
-            b["dom_flags"] = t.zeros((B,), dtype=t.int32, device=dev)
+        if self.hd is not None:  # compact [B, top_k] lists: what the search writes and what the fusion reads
+            b["dom_ids"] = t.full((B, cfg.top_k), -1, dtype=t.int64, device=dev)
+            b["dom_scores"] = t.zeros((B, cfg.top_k), dtype=t.float32, device=dev)
+            b["dom_flags"] = t.ones((B,), dtype=t.int32, device=dev)
         if self.world > 1:
             b["gathered"] = t.empty((self.world, layout.nbytes), dtype=t.uint8, device=dev)
-            b["m_ids"] = t.empty((n_mod, B, kp), dtype=t.int64, device=dev)
-            b["m_scores"] = t.empty((n_mod, B, kp), dtype=t.float32, device=dev)
+            b["m_ids"] = t.empty((n_main, B, kp), dtype=t.int64, device=dev)
+            b["m_scores"] = t.empty((n_main, B, kp), dtype=t.float32, device=dev)
+            if self.hd is not None:
+                b["m_dom_ids"] = t.empty((B, cfg.top_k), dtype=t.int64, device=dev)
+                b["m_dom_scores"] = t.empty((B, cfg.top_k), dtype=t.float32, device=dev)
         self._bufs[B] = b
         return b
+
+    def _search_domain(self, b: dict, domain_q, B: int, stream: int):
+        """Third list: top_k of the domain shard into the compact buffers, mirrored into the pack for the exchange."""
+        cfg = self.cfg
+        b["use_domain"] = domain_q is not None
+        if self.hd is None:
+            return
+        m = b["n_mod"] - 1
+        if domain_q is None:  # nothing to exchange for this batch: an empty, proven list
+            b["ids"][m].fill_(-1)
+            b["flags"][m].fill_(1)
+            return
+        self.hd.search_dense_dev(domain_q.data_ptr(), B, cfg.top_k, b["dom_ids"].data_ptr(), b["dom_scores"].data_ptr(),
+                                 b["dom_flags"].data_ptr(), 0, stream)
+        b["flags"][m].copy_(b["dom_flags"])
+        if self.world > 1:
+            b["ids"][m, :, :cfg.top_k].copy_(b["dom_ids"])
+            b["scores"][m, :, :cfg.top_k].copy_(b["dom_scores"])
 
     # ------------------------------------------------------------------ one batch
     def search(self, q, sparse=None, domain_q=None) -> dict:
@@ -194,8 +235,8 @@ class HybridSearchEngine:
         if self.stream is not None and self.torch.cuda.current_stream(self.device) != self.stream:
             with self.torch.cuda.stream(self.stream):
                 return self.search(q, sparse, domain_q)
-        if domain_q is not None and (self.hd is None or self.world > 1):
-            raise ValueError("domain queries need an engine built with domain_handle on a single shard")
+        if domain_q is not None and self.hd is None:
+            raise ValueError("domain queries need an engine built with domain_handle")
         t, cfg = self.torch, self.cfg
         B = q.shape[0]
         b = self._buffers(B)
@@ -210,27 +251,36 @@ class HybridSearchEngine:
         else:
             self.h.search_dense_dev(q.data_ptr(), B, kp, b["ids"][0].data_ptr(), b["scores"][0].data_ptr(),
                                     b["flags"][0].data_ptr(), 0, stream)
-        b["use_domain"] = domain_q is not None
-        if domain_q is not None:
-            self.hd.search_dense_dev(domain_q.data_ptr(), B, cfg.top_k, b["dom_ids"].data_ptr(),
-                                     b["dom_scores"].data_ptr(), b["dom_flags"].data_ptr(), 0, stream)
+        self._search_domain(b, domain_q, B, stream)
         return self._post_lists(b, B, stream)
 
     def _post_lists(self, b: dict, B: int, stream: int) -> dict:
         """Everything after the per-shard lists exist: [exchange + merge] -> RRF -> rerank."""
         cfg, kp = self.cfg, b["kp"]
         ids, scores = b["ids"], b["scores"]
+        dom = b["use_domain"]
+        dom_ids = b.get("dom_ids")
         if self.world > 1:
             g = exchange_lists(b["pack"], self.world, self.dist, self.group, out=b["gathered"])
-            for m in range(b["n_mod"]):
+            for m in range(b["n_main"]):
                 sc_off, id_off, sc_stride, id_stride = b["layout"].merge_args(m)
                 nat.merge_topk_dev(g.data_ptr() + sc_off, g.data_ptr() + id_off, self.world, B, kp, kp,
                                    b["m_ids"][m].data_ptr(), b["m_scores"][m].data_ptr(), stream,
                                    score_stride=sc_stride, id_stride=id_stride)
             ids, scores = b["m_ids"], b["m_scores"]
-        dom = b.get("use_domain", False)
+            if dom:
+                sc_off, id_off, sc_stride, id_stride = b["layout"].merge_args(b["n_mod"] - 1)
+                nat.merge_topk_dev(g.data_ptr() + sc_off, g.data_ptr() + id_off, self.world, B, kp, cfg.top_k,
+                                   b["m_dom_ids"].data_ptr(), b["m_dom_scores"].data_ptr(), stream,
+                                   score_stride=sc_stride, id_stride=id_stride)
+                dom_ids = b["m_dom_ids"]
+            # a list is proven iff every rank proved its part: identical on all ranks, so they all take the same
+            # repair decision (resolve_inexact)
+            b["agg_flags"] = b["layout"].flags_view(g).amin(dim=0)
+        else:
+            b["agg_flags"] = b["flags"]
         nat.fuse_rrf_dev(ids[0].data_ptr(), kp, ids[1].data_ptr() if cfg.use_sparse else 0,
-                         kp if cfg.use_sparse else 0, b["dom_ids"].data_ptr() if dom else 0, cfg.top_k if dom else 0, B,
+                         kp if cfg.use_sparse else 0, dom_ids.data_ptr() if dom else 0, cfg.top_k if dom else 0, B,
                          cfg.dense_weight, cfg.sparse_weight, cfg.domain_weight, cfg.rrf_k,
                          cfg.top_k, b["fused_ids"].data_ptr(), b["fused_scores"].data_ptr(),
                          b["fused_methods"].data_ptr(), b["fused_n"].data_ptr(), stream)
@@ -242,31 +292,46 @@ class HybridSearchEngine:
         b["list_ids"], b["list_scores"] = ids, scores
         return b
 
-    def resolve_inexact(self, b: dict, q_host: np.ndarray, sparse_host=None, drop_ratio: float = 0.0) -> int:
+    def resolve_inexact(self, b: dict, q_host: np.ndarray, sparse_host=None, drop_ratio: float = 0.0,
+                        domain_q_host: Optional[np.ndarray] = None) -> int:
         """The device forms report, per (modality, query), whether the list is PROVEN exact.  For the rare ones
         that are not (ties at the candidate cut), redo those queries through the host forms — which widen the
-        candidate set until the proof holds — patch the lists and redo fusion/rerank.  `sparse_host` holds the
-        queries as given to pack_sparse_queries (before the drop).  Returns the number of lists redone; call after
-        synchronising the batch.  Single-shard only: every rank of a sharded corpus must call its own."""
+        candidate set until the proof holds — patch the lists and redo exchange / fusion / rerank.  `sparse_host`
+        holds the queries as given to pack_sparse_queries (before the drop).  Call after synchronising the batch.
+
+        On a sharded corpus EVERY rank calls this with the same arguments: the exchanged flags (minimum over ranks,
+        the same on every rank) decide which queries are redone, each rank repairs the lists ITS shard could not
+        prove, and the exchange is repeated — collectively, and only if some list was unproven somewhere.
+        Returns the number of (modality, query) lists this rank redid."""
         t = self.torch
-        flags = b["flags"].cpu().numpy()
+        agg = b["agg_flags"].cpu().numpy()
+        if agg.min() == 1:
+            return 0
+        own = b["flags"].cpu().numpy()
         redone = 0
-        B = flags.shape[1]
+        B = own.shape[1]
         for m in range(b["n_mod"]):
-            bad = np.nonzero(flags[m] == 0)[0]
+            bad = np.nonzero((agg[m] == 0) & (own[m] == 0))[0]
             if not len(bad):
                 continue
             if m == 0:
                 ids, sc = self.h.search_dense(np.ascontiguousarray(q_host[bad]), b["kp"])
-            else:
+            elif m < b["n_main"]:
                 ids, sc = self.h.search_sparse([sparse_host[i] for i in bad], b["kp"], drop_ratio)
+            else:
+                ids, sc = self.hd.search_dense(np.ascontiguousarray(domain_q_host[bad]), self.cfg.top_k)
+                sel = t.from_numpy(bad).to(self.device)
+                b["dom_ids"].index_copy_(0, sel, t.from_numpy(ids).to(self.device))
+                b["dom_scores"].index_copy_(0, sel, t.from_numpy(sc).to(self.device))
+                pad = b["kp"] - self.cfg.top_k
+                ids = np.pad(ids, ((0, 0), (0, pad)), constant_values=-1)
+                sc = np.pad(sc, ((0, 0), (0, pad)))
             sel = t.from_numpy(bad).to(self.device)
             b["ids"][m].index_copy_(0, sel, t.from_numpy(ids).to(self.device))
             b["scores"][m].index_copy_(0, sel, t.from_numpy(sc).to(self.device))
             b["flags"][m].index_fill_(0, sel, 1)
             redone += len(bad)
-        if redone:
-            self._post_lists(b, B, t.cuda.current_stream(self.device).cuda_stream)
+        self._post_lists(b, B, t.cuda.current_stream(self.device).cuda_stream)
         return redone
 
     def upload_sparse(self, packed):
@@ -285,12 +350,13 @@ class PipelinedSearchEngine(HybridSearchEngine):
     on the LIGHT stream and so hides behind the next batch's scans.  Scans never overlap each
     other, which keeps the event-timed scan (roofline) meaningful.  Results of `submit` are valid
     once the light stream has passed the returned `done` event (or after `synchronize()`).
-    Requires the sparse modality (the two-phase C entry points are hybrid).
+    Requires the sparse modality (the two-phase C entry points are hybrid).  The optional domain
+    list (engine built with domain_handle) is searched on the heavy stream right behind the batch's scans.
     """
 
     def __init__(self, handle, config: Optional[EngineConfig] = None, process_group=None, device: Optional[str] = None,
-                 depth: int = 2):
-        super().__init__(handle, config, process_group, device)
+                 depth: int = 2, domain_handle=None):
+        super().__init__(handle, config, process_group, device, domain_handle=domain_handle)
         if not self.cfg.use_sparse:
             raise ValueError("PipelinedSearchEngine needs the sparse modality")
         if not 1 <= depth <= 4:
@@ -324,8 +390,10 @@ class PipelinedSearchEngine(HybridSearchEngine):
             self._slot_bufs[slot][B] = b
         return b
 
-    def submit(self, q, sparse) -> dict:
+    def submit(self, q, sparse, domain_q=None) -> dict:
         t, cfg = self.torch, self.cfg
+        if domain_q is not None and self.hd is None:
+            raise ValueError("domain queries need an engine built with domain_handle")
         B = q.shape[0]
         slot = self._n % self.depth
         self._n += 1
@@ -336,6 +404,8 @@ class PipelinedSearchEngine(HybridSearchEngine):
         self.heavy.wait_event(b["done"])  # the batch that used this slot before has been finished
         self.h.hybrid_scan_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, nnz, int(max_nnz),
                                kp, slot, self.heavy.cuda_stream)
+        with t.cuda.stream(self.heavy):
+            self._search_domain(b, domain_q, B, self.heavy.cuda_stream)
         b["scan_done"].record(self.heavy)
         self.light.wait_event(b["scan_done"])
         with t.cuda.stream(self.light):
@@ -353,4 +423,5 @@ class PipelinedSearchEngine(HybridSearchEngine):
         self.light.synchronize()
 
     def all_flags_exact(self) -> bool:
-        return all(bool(b["flags"].min().item() == 1) for slot in self._slot_bufs for b in slot.values())
+        return all(bool(b["agg_flags"].min().item() == 1) for slot in self._slot_bufs for b in slot.values()
+                   if "agg_flags" in b)

@@ -161,9 +161,13 @@ class MilvusIndexManager:
             self.collections["domain_index"] = ShardCollection(self, "domain_index", "dense", self._domain,
                                                                self.domain_dim, "COSINE")
 
-    def attach_shards(self, handles, rows_of=None, synthetic_rows: int = 0):
+    def attach_shards(self, handles, rows_of=None, synthetic_rows: int = 0, process_group=None, first_row: int = 0):
         """Adopt already-built shard handles as the semantic (+ sparse) collection — e.g. the shard a benchmark has
-        just filled.  rows_of[s] = global row of every local row of shard s (default: shard s follows shard s-1)."""
+        just filled.  rows_of[s] = global row of every local row of shard s (default: shard s follows shard s-1).
+
+        With `process_group` (torch.distributed, one process per GPU) the collection spans the group's ranks: this
+        rank's handle holds global rows [first_row, first_row + its rows) and must carry that offset
+        (ShardHandle.set_row_offset); rank 0 answers `search`/`retrieve`, the other ranks call `serve()`."""
         if not hasattr(self, "_native"):
             self._connect()
         handles = list(handles)
@@ -172,9 +176,18 @@ class MilvusIndexManager:
             for h in handles:
                 rows_of.append(np.arange(base, base + h.num_rows, dtype=np.int64))
                 base += h.num_rows
-        self._main = ShardSet(handles)
-        self._main.rows_of = [np.asarray(r, dtype=np.int64) for r in rows_of]
-        self._main._n = int(sum(len(r) for r in rows_of))
+        local = ShardSet(handles)
+        local.rows_of = [np.asarray(r, dtype=np.int64) for r in rows_of]
+        local._n = int(sum(len(r) for r in rows_of))
+        if process_group is not None:
+            import torch.distributed as dist
+            from .shards import CollectiveShardSet
+            if len(handles) != 1:
+                raise ValueError("the torchrun form takes one shard handle per process")
+            group = None if process_group is True else process_group
+            self._main = CollectiveShardSet(local, first_row, dist, group)
+        else:
+            self._main = local
         self.devices = [h.device for h in handles]
         self.collections["semantic_index"] = ShardCollection(self, "semantic_index", "dense", self._main,
                                                              self.semantic_dim, "COSINE")
@@ -182,6 +195,13 @@ class MilvusIndexManager:
             self.collections["sparse_index"] = ShardCollection(self, "sparse_index", "sparse", self._main,
                                                                self.sparse_dim, "IP")
         self._synthetic_rows = int(synthetic_rows)
+
+    def serve(self):
+        """Ranks > 0 of the torchrun form: answer rank 0's searches until it calls stop_workers()."""
+        self._main.serve()
+
+    def stop_workers(self):
+        self._main.stop_workers()
 
     # ------------------------------------------------------------------ host columns
     def _columns(self) -> Dict[str, np.ndarray]:

@@ -184,3 +184,143 @@ class ShardSet:
         self.handles = list(handles)
         self.rows_of = [np.asarray(r, dtype=np.int64) for r in rows_of]
         self._n = int(sum(len(r) for r in self.rows_of))
+
+
+class CollectiveShardSet:
+    """The torchrun form: one PROCESS per GPU, each owning the shard(s) of a contiguous global row range, searched
+    as one collection from rank 0.
+
+    Rank 0 is the front end (it owns the payload columns and answers `search`); the other ranks run `serve()`.
+    One search = broadcast of a fixed-size header, broadcast of the query (+ the packed filter mask, if any), the
+    per-rank HIP search, ONE gather of the packed per-rank lists to rank 0, the same merge as `ShardSet`.  The
+    collectives are torch.distributed's (backend "nccl" = RCCL over xGMI on a GPU node; "gloo" in the CPU tests and
+    one-GPU rehearsals); searches are serialised by a lock, so every rank sees the same sequence of commands.
+
+    The local shard must already carry its global row numbers (ShardHandle.set_row_offset(first_row)), i.e. a
+    local ShardSet of one handle; `first_row`/`n_local` say which slice of a global filter mask is this rank's."""
+
+    OP_STOP, OP_DENSE, OP_SPARSE = 0, 1, 2
+
+    def __init__(self, local: ShardSet, first_row: int, dist, group=None, device=None):
+        import threading
+
+        import torch
+        self.torch, self.dist, self.group = torch, dist, group
+        self.local, self.first_row = local, int(first_row)
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.dev = torch.device(device) if device is not None else (
+            torch.device("cuda", local.device) if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+        self._lock = threading.Lock()
+        n = torch.tensor([local.num_rows, local.num_sparse_rows], dtype=torch.int64, device=self.dev)
+        dist.all_reduce(n, group=group)
+        self._n_rows, self._n_sparse = int(n[0]), int(n[1])
+
+    # shape, as ShardSet
+    n_shards = property(lambda self: self.world)
+    first = property(lambda self: self.local.first)
+    device = property(lambda self: self.local.device)
+    num_rows = property(lambda self: self._n_rows)
+    num_sparse_rows = property(lambda self: self._n_sparse)
+    rows_of = property(lambda self: self.local.rows_of)
+
+    def finalize(self):
+        self.local.finalize()
+
+    def close(self):
+        self.local.close()
+
+    # ------------------------------------------------------------------ protocol
+    def _bcast(self, t):
+        self.dist.broadcast(t, src=0, group=self.group)
+        return t
+
+    def _header(self, values=None):
+        t = self.torch
+        h = t.zeros(8, dtype=t.int64, device=self.dev)
+        if values is not None:
+            h[: len(values)] = t.tensor(values, dtype=t.int64)
+        return self._bcast(h).tolist()
+
+    def _exchange_mask(self, keep, n_rows: int, has_mask: bool):
+        """rank 0 broadcasts the packed filter over GLOBAL rows; every rank cuts out its own rows."""
+        if not has_mask:
+            return None
+        t = self.torch
+        packed = t.from_numpy(np.packbits(keep, bitorder="little")).to(self.dev) if self.rank == 0 else \
+            t.empty((n_rows + 7) // 8, dtype=t.uint8, device=self.dev)
+        bits = np.unpackbits(self._bcast(packed).cpu().numpy(), bitorder="little")[:n_rows].astype(bool)
+        n_local = self.local.num_rows if self.local.num_rows else self.local.num_sparse_rows
+        return bits[self.first_row:self.first_row + n_local]
+
+    def _collect(self, ids: np.ndarray, scores: np.ndarray, k: int):
+        """ONE gather: [B, 2k] int64 per rank = ids, then the fp32 score bits."""
+        t = self.torch
+        B = ids.shape[0]
+        pack = np.concatenate([ids.astype(np.int64), scores.astype(np.float32).view(np.int32).astype(np.int64)], axis=1)
+        mine = t.from_numpy(np.ascontiguousarray(pack)).to(self.dev)
+        parts = [t.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(mine, parts, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        parts = [p.cpu().numpy() for p in parts]
+        return merge_lists([p[:, :k] for p in parts],
+                           [p[:, k:].astype(np.int32).view(np.float32).reshape(B, k) for p in parts], k)
+
+    def _run(self, op: int, B: int, k: int, extra: int, has_mask: bool, drop_bits: int, payload, keep):
+        t = self.torch
+        if op == self.OP_DENSE:
+            dim = extra
+            q = payload if self.rank == 0 else t.empty((B, dim), dtype=t.float32, device=self.dev)
+            q = self._bcast(q).cpu().numpy()
+            local_keep = self._exchange_mask(keep, self._n_rows, has_mask)
+            ids, sc = self.local.search_dense(q, k, local_keep)
+        else:
+            nnz = extra
+            if self.rank == 0:
+                ptr, idx, val = payload
+            else:
+                ptr = t.empty(B + 1, dtype=t.int64, device=self.dev)
+                idx = t.empty(nnz, dtype=t.int32, device=self.dev)
+                val = t.empty(nnz, dtype=t.float32, device=self.dev)
+            ptr, idx, val = (self._bcast(x).cpu().numpy() for x in (ptr, idx, val))
+            local_keep = self._exchange_mask(keep, self._n_sparse, has_mask)
+            queries = [(idx[ptr[b]:ptr[b + 1]], val[ptr[b]:ptr[b + 1]]) for b in range(B)]
+            drop = float(np.array([drop_bits], dtype=np.int64).view(np.float64)[0])
+            ids, sc = self.local.search_sparse(queries, k, drop, local_keep)
+        return self._collect(ids, sc, k)
+
+    # ------------------------------------------------------------------ rank 0
+    def search_dense(self, q: np.ndarray, k: int, keep: Optional[np.ndarray] = None):
+        t = self.torch
+        q = np.ascontiguousarray(np.atleast_2d(q), dtype=np.float32)
+        with self._lock:
+            self._header([self.OP_DENSE, q.shape[0], k, q.shape[1], int(keep is not None), 0])
+            return self._run(self.OP_DENSE, q.shape[0], k, q.shape[1], keep is not None, 0,
+                             t.from_numpy(q).to(self.dev), keep)
+
+    def search_sparse(self, queries, k: int, drop_ratio: float = 0.0, keep: Optional[np.ndarray] = None):
+        t = self.torch
+        ptr = np.zeros(len(queries) + 1, dtype=np.int64)
+        for b, (qi, _) in enumerate(queries):
+            ptr[b + 1] = ptr[b] + len(qi)
+        idx = np.concatenate([np.asarray(qi, np.int32) for qi, _ in queries]) if ptr[-1] else np.zeros(0, np.int32)
+        val = np.concatenate([np.asarray(qv, np.float32) for _, qv in queries]) if ptr[-1] else np.zeros(0, np.float32)
+        drop_bits = int(np.array([drop_ratio], dtype=np.float64).view(np.int64)[0])
+        with self._lock:
+            self._header([self.OP_SPARSE, len(queries), k, int(ptr[-1]), int(keep is not None), drop_bits])
+            payload = tuple(t.from_numpy(x).to(self.dev) for x in (ptr, idx, val))
+            return self._run(self.OP_SPARSE, len(queries), k, int(ptr[-1]), keep is not None, drop_bits, payload, keep)
+
+    def stop_workers(self):
+        with self._lock:
+            self._header([self.OP_STOP])
+
+    # ------------------------------------------------------------------ ranks > 0
+    def serve(self):
+        """Answer rank 0's searches until it sends OP_STOP."""
+        while True:
+            op, B, k, extra, has_mask, drop_bits, _, _ = self._header()
+            if op == self.OP_STOP:
+                return
+            self._run(int(op), int(B), int(k), int(extra), bool(has_mask), int(drop_bits), None, None)

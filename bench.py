@@ -331,10 +331,14 @@ def main():
     scan_bytes = h.dense_scan_bytes
     achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
 
-    # ---- p50 latency of single-query retrieve() through the Python API (N=1) --------------------------------
+    # ---- p50 latency of single-query retrieve() through the Python API ---------------------------------------------
+    # N = 1: the manager holds the one shard.  N > 1: the collection spans the ranks (torchrun form of the sharded
+    # manager): rank 0 calls retrieve(), every rank searches its shard, one gather per modality brings the lists back.
     latency = None
-    if world == 1 and not args.no_latency and args.latency_queries > 0:
-        latency = measure_latency(h, Q, SQ, args, use_sparse)
+    if not args.no_latency and args.latency_queries > 0:
+        latency = measure_latency(h, Q, SQ, args, use_sparse, world, rank, lo, N)
+        if world > 1:
+            dist.barrier()
 
     # ---- CPU baseline (N=1): the reference path with Milvus replaced by numpy/scipy, on the subsample -----------
     cpu = None
@@ -397,16 +401,24 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_latency(h, Q, SQ, args, use_sparse):
+def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_total=None):
     """p50/p95 wall time of `await HybridRetriever.retrieve(query, profile_hint="default")` for single
-    queries: host buffers in, Python dicts out (string ids), both searches + device RRF."""
+    queries: host buffers in, Python dicts out (string ids), both searches + device RRF.  With world > 1 the
+    searches fan out over the ranks (ranks > 0 serve) and the times are rank 0's."""
     import asyncio
     from advanced_rag.constants import RetrievalConstants
     from advanced_rag.indexing import MilvusIndexManager
     from advanced_rag.retrieval import HybridRetriever, RetrievalConfig
 
     mgr = MilvusIndexManager(semantic_dim=args.dim, sparse_dim=SPARSE_DIM, connect=False)
-    mgr.attach_shards([h], synthetic_rows=h.num_rows)
+    if world > 1:
+        mgr.attach_shards([h], rows_of=[np.arange(h.num_rows)], synthetic_rows=n_total, process_group=True,
+                          first_row=first_row)
+        if rank != 0:
+            mgr.serve()
+            return None
+    else:
+        mgr.attach_shards([h], synthetic_rows=h.num_rows)
     flatQ = Q.reshape(-1, args.dim)
     flatS = [s for batch in SQ for s in batch]
 
@@ -459,10 +471,13 @@ def measure_latency(h, Q, SQ, args, use_sparse):
                 lat2.append(dt)
         return lat2
 
-    with contextlib.redirect_stdout(sys.stderr):
+    with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):  # the pipeline prints a line per SLA / risk warning
         lat2 = asyncio.run(run_pipeline())
+    if world > 1:
+        mgr.stop_workers()
     mgr.embedding_executor.shutdown(wait=False)
-    return {"p50_retrieve_ms": float(np.percentile(lat, 50)), "p95_retrieve_ms": float(np.percentile(lat, 95)),
+    return {"retrieve_shards": world,
+            "p50_retrieve_ms": float(np.percentile(lat, 50)), "p95_retrieve_ms": float(np.percentile(lat, 95)),
             "p50_pipeline_retrieve_ms": float(np.percentile(lat2, 50)),
             "p95_pipeline_retrieve_ms": float(np.percentile(lat2, 95)), "latency_queries": n}
 

@@ -131,3 +131,111 @@ def test_pack_sparse_queries_matches_oracle_drop():
         oi, ov = oracle.drop_query(qi, qv, 0.2)
         assert np.array_equal(idx[ptr[b]:ptr[b + 1]], oi) and np.array_equal(val[ptr[b]:ptr[b + 1]], ov)
     assert mx == 80
+
+
+class _OracleShard:
+    """Stands in for a ShardHandle on a box without a GPU: the oracle over one contiguous row range, with the
+    handle's search signatures (global row ids through the row offset, packed local row masks)."""
+
+    def __init__(self, X, ptr, idx, val, lo, hi, sparse_dim):
+        import oracle
+        self.o, self.X, self.lo, self.hi = oracle, X[lo:hi], lo, hi
+        self.ptr, self.idx, self.val = ptr[lo:hi + 1] - ptr[lo], idx[ptr[lo]:ptr[hi]], val[ptr[lo]:ptr[hi]]
+        self.device, self.sparse_dim = 0, sparse_dim
+        self.num_rows = self.num_sparse_rows = hi - lo
+
+    def search_dense(self, q, k, mask=None):
+        return self.o.dense_search(self.X, q, k, self.o.COSINE, mask, row_offset=self.lo)
+
+    def search_sparse(self, queries, k, drop, mask=None):
+        return self.o.sparse_search(self.ptr, self.idx, self.val, queries, k, drop, mask, row_offset=self.lo)
+
+    def fuse_rrf(self, a, b, c, wa, wb, wc, rrf_k):
+        return self.o.rrf(a, b, c, wa, wb, wc, rrf_k)
+
+    def finalize(self):
+        pass
+
+    def close(self):
+        pass
+
+
+def _collective_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "advanced-rag-milvus_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import asyncio
+    import oracle
+    from advanced_rag import HybridRetriever, MilvusIndexManager, RetrievalConfig
+    from advanced_rag.constants import RetrievalConstants
+    from advanced_rag.engine import shard_range
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        X, ptr, idx, val, Q, SQ = _corpus()
+        n, V = X.shape[0], 400
+        lo, hi = shard_range(n, rank, world, align=64)
+        mgr = MilvusIndexManager(semantic_dim=X.shape[1], sparse_dim=V, connect=False)
+        mgr._native = None  # no library on this box: the shard below is the oracle
+        mgr.attach_shards([_OracleShard(X, ptr, idx, val, lo, hi, V)], rows_of=[np.arange(hi - lo)], synthetic_rows=n,
+                          process_group=True, first_row=lo)
+        assert mgr._main.num_rows == n and mgr._main.n_shards == world
+        if rank != 0:
+            mgr.serve()
+            ret[rank] = True
+            return
+        cs = mgr._main
+        keep = np.random.default_rng(1).random(n) < 0.3
+        packed = np.packbits(keep, bitorder="little")
+        for B in (1, 6):
+            gi, gs = cs.search_dense(Q[:B], 40)
+            oi, os_ = oracle.dense_search(X, Q[:B], 40, oracle.COSINE)
+            assert np.array_equal(gi, oi) and np.array_equal(gs.view(np.uint32), os_.view(np.uint32))
+            gi, gs = cs.search_dense(Q[:B], 40, keep)
+            oi, os_ = oracle.dense_search(X, Q[:B], 40, oracle.COSINE, packed)
+            assert np.array_equal(gi, oi) and np.array_equal(gs.view(np.uint32), os_.view(np.uint32))
+            gi, gs = cs.search_sparse(SQ[:B], 40, 0.2)
+            oi, os_ = oracle.sparse_search(ptr, idx, val, SQ[:B], 40, 0.2)
+            assert np.array_equal(gi, oi) and np.array_equal(gs.view(np.uint32), os_.view(np.uint32))
+            gi, gs = cs.search_sparse(SQ[:B], 40, 0.0, keep)
+            oi, os_ = oracle.sparse_search(ptr, idx, val, SQ[:B], 40, 0.0, packed)
+            assert np.array_equal(gi, oi) and np.array_equal(gs.view(np.uint32), os_.view(np.uint32))
+        assert cs.search_dense(Q[:1], 40)[0][0, 0] == 100  # the cross-rank tie: lower global row first
+
+        # retrieve() on rank 0 over the two ranks == the single-process oracle chain
+        class Gen:
+            def encode_semantic(self, text):
+                return Q[int(text)]
+
+            def encode_sparse(self, text):
+                qi, qv = SQ[int(text)]
+                return {"indices": qi.tolist(), "values": qv.tolist()}
+
+        mgr.embedding_generator = Gen()
+        RetrievalConstants.TIMEOUT_SECONDS = 60.0
+        for q in range(3):
+            from advanced_rag.embedding_cache import initialize_caches
+            initialize_caches()
+            out = asyncio.run(HybridRetriever(mgr, RetrievalConfig(top_k=20)).retrieve(str(q), profile_hint="default"))
+            di, _ = oracle.dense_search(X, Q[q:q + 1], 40, oracle.COSINE)
+            si, _ = oracle.sparse_search(ptr, idx, val, SQ[q:q + 1], 40, 0.2)
+            fi, fs, _ = oracle.rrf(di[0], si[0][si[0] >= 0], (), 0.7, 0.3, 0.2, 60)
+            assert [o["id"] for o in out] == [MilvusIndexManager.synthetic_id(int(r)) for r in fi[:20]]
+            assert [o["score"] for o in out] == [float(s) for s in fs[:20]]
+        mgr.stop_workers()
+        ret[rank] = True
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_collective_shard_set_serves_retrieve_across_two_ranks():
+    """The torchrun form of the sharded collection (CollectiveShardSet behind MilvusIndexManager.attach_shards):
+    rank 0 searches / retrieves, rank 1 serves; the per-rank search is the oracle here (no GPU), the protocol —
+    header, query and mask broadcasts, the one gather, the merge — is the product's."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_collective_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
