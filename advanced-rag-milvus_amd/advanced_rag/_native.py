@@ -51,6 +51,8 @@ _SIGNATURES = {
     "hr_finalize": (_c.c_int, [_c.c_void_p]),
     "hr_save": (_c.c_int, [_c.c_void_p, _c.c_char_p]),
     "hr_load": (_c.c_int, [_c.c_char_p, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "hr_get_info": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int32),
+                               _c.POINTER(_c.c_int64)]),
     "hr_num_rows": (_c.c_int64, [_c.c_void_p]),
     "hr_num_sparse_rows": (_c.c_int64, [_c.c_void_p]),
     "hr_device_bytes": (_c.c_int64, [_c.c_void_p]),
@@ -173,8 +175,8 @@ class ShardHandle:
     @classmethod
     def load(cls, path: str, dim: int, dtype: int = HR_F16, metric: int = HR_METRIC_COSINE, sparse_dim: int = 0,
              device: int = 0) -> "ShardHandle":
-        """Load a snapshot; dim/dtype/metric/sparse_dim describe what the caller expects (checked against the file
-        through the searches' own argument checks)."""
+        """Load a snapshot; dim/dtype/metric/sparse_dim describe what the caller expects and are checked against what
+        the file holds (a mismatch would make later calls read query or row buffers of the wrong size)."""
         lib = load_library()
         h = ctypes.c_void_p()
         rc = lib.hr_load(os.fsencode(path), device, ctypes.byref(h))
@@ -183,6 +185,14 @@ class ShardHandle:
             if rc == 1:
                 raise ValueError(msg)
             raise HbmRagError(rc, msg)
+        f_dim, f_sdim = ctypes.c_int64(), ctypes.c_int64()
+        f_dtype, f_metric = ctypes.c_int32(), ctypes.c_int32()
+        lib.hr_get_info(h, ctypes.byref(f_dim), ctypes.byref(f_dtype), ctypes.byref(f_metric), ctypes.byref(f_sdim))
+        got = (f_dim.value, f_dtype.value, f_metric.value, f_sdim.value)
+        if got != (dim, dtype, metric, sparse_dim):
+            lib.hr_destroy(h)
+            raise ValueError(f"snapshot {path} holds (dim, dtype, metric, sparse_dim) = {got}, expected "
+                             f"{(dim, dtype, metric, sparse_dim)}")
         return cls(dim, dtype, metric, sparse_dim, device, _adopt=h.value)
 
     # -- ingest

@@ -38,16 +38,25 @@ def shard_range(n_rows: int, rank: int, world: int, align: int = 1) -> Tuple[int
     return lo, min(n_rows, lo + per)
 
 
-def pack_sparse_queries(queries: Sequence[Tuple[Sequence[int], Sequence[float]]], drop_ratio: float = 0.0):
+def pack_sparse_queries(queries: Sequence[Tuple[Sequence[int], Sequence[float]]], drop_ratio: float = 0.0,
+                        sparse_dim: Optional[int] = None):
     """Host prep of a sparse query batch for the device form: apply
     drop_ratio_search (smallest |value| first; among equals the later entry),
-    sort by index, build CSR.  Returns (indptr int64, idx int32, val float32, max_nnz)."""
+    sort by index, build CSR.  Returns (indptr int64, idx int32, val float32, max_nnz).
+    Indices must be distinct, non-negative and (when sparse_dim is given) below sparse_dim — what
+    hr_search_sparse checks for the host form."""
     ptr = [0]
     idx_parts, val_parts = [], []
     max_nnz = 0
     for qi, qv in queries:
         qi = np.asarray(qi, dtype=np.int32)
         qv = np.asarray(qv, dtype=np.float32)
+        if qi.shape != qv.shape:
+            raise ValueError("sparse query indices/values length mismatch")
+        if qi.size and (qi.min() < 0 or (sparse_dim is not None and qi.max() >= sparse_dim)):
+            raise ValueError(f"sparse query index out of range [0, {sparse_dim})")
+        if np.unique(qi).size != qi.size:
+            raise ValueError("duplicate sparse query index")
         n_drop = int(np.floor(drop_ratio * len(qi)))
         if n_drop:
             order = np.lexsort((-np.arange(len(qi)), np.abs(qv)))  # |v| asc, later entry first

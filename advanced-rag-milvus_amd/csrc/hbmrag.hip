@@ -46,6 +46,27 @@ struct DevBuf {
         if (e == hipSuccess) cap = want;
         return e;
     }
+    // Capacity for `bytes`, KEEPING the first `keep` bytes (device-to-device copy on stream s into a buffer 1.5x the
+    // size asked for, so that repeated appends cost amortised O(appended bytes)).
+    hipError_t grow(size_t bytes, size_t keep, hipStream_t s) {
+        if (bytes <= cap) return hipSuccess;
+        void* np_ = nullptr;
+        const size_t want = bytes + bytes / 2 + 256;
+        hipError_t e = hipMalloc(&np_, want);
+        if (e != hipSuccess) return e;
+        if (p && keep) {
+            e = hipMemcpyAsync(np_, p, keep, hipMemcpyDeviceToDevice, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                (void)hipFree(np_);
+                return e;
+            }
+        }
+        if (p) (void)hipFree(p);
+        p = np_;
+        cap = want;
+        return hipSuccess;
+    }
     void release() {
         if (p) (void)hipFree(p);
         p = nullptr;
@@ -57,6 +78,7 @@ struct DevBuf {
 enum Phase { PH_PREP = 0, PH_SCAN, PH_GSEL, PH_REFINE, PH_TOPK, PH_SSCAN, PH_SGSEL, PH_SREFINE, PH_STOPK, PH_COUNT };
 
 struct Workspace {
+    std::mutex mu;                 // held while one call enqueues: calls sharing a workspace must not interleave their kernels
     hipStream_t stream = nullptr;  // own stream (host-form calls)
     hipStream_t side = nullptr;    // side stream + events of hr_search_hybrid_dev
     hipEvent_t ev_scan = nullptr, ev_side = nullptr;
@@ -106,11 +128,12 @@ struct hr_index {
     DevBuf stage;  // ingest staging
     hipStream_t ingest_stream = nullptr;
 
-    // sparse shard: host CSR staging + device copies
-    std::vector<int64_t> h_indptr{0};
-    std::vector<int32_t> h_idx;
-    std::vector<float> h_val;
-    int64_t n_sparse = 0, n_sparse_built = -1;
+    // sparse shard: the CSR lives on the device; the host only stages the rows appended since the last hr_finalize
+    std::vector<int64_t> pend_indptr{0};  // relative to the first pending entry
+    std::vector<int32_t> pend_idx;
+    std::vector<float> pend_val;
+    std::vector<int64_t> h_range_base{0};  // first posting of every range's block (+ total), host copy
+    int64_t n_sparse = 0, n_sparse_built = 0, nnz_built = 0;
     float max_sparse_abs = 0.f;  // max |doc weight|: bounds the scan's fixed-point range
     DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post;  // post: packed (fp16 weight | u16 accumulator slot)
     DevBuf idle_post;  // 64 x 4 idle postings: what scan lanes with nothing to fetch read (sparse.h)
@@ -198,12 +221,35 @@ void give_ws(hr_index* h, Workspace* w) {
     std::lock_guard<std::mutex> g(h->pool_mu);
     h->free_ws.push_back(w);
 }
-Workspace* ws_for_stream(hr_index* h, void* stream) {
+// The workspace of a caller-owned stream, returned LOCKED: `*_dev` calls that share a stream share its workspace
+// (query fragments, group maxima, candidates), so one call's enqueue must not interleave with another's — their
+// kernels then run in stream order.  The map is pruned when it grows: a long-lived handle used from many short-lived
+// streams would otherwise keep every stream's buffers for ever.
+constexpr size_t kMaxStreamWorkspaces = 32;
+Workspace* ws_for_stream(hr_index* h, void* stream, std::unique_lock<std::mutex>& held) {
     std::lock_guard<std::mutex> g(h->pool_mu);
     auto it = h->stream_ws.find(stream);
-    if (it != h->stream_ws.end()) return it->second;
-    Workspace* w = new (std::nothrow) Workspace();
-    if (w) h->stream_ws[stream] = w;
+    Workspace* w = nullptr;
+    if (it != h->stream_ws.end()) {
+        w = it->second;
+    } else {
+        if (h->stream_ws.size() >= kMaxStreamWorkspaces) {
+            for (auto jt = h->stream_ws.begin(); jt != h->stream_ws.end();) {
+                Workspace* old = jt->second;
+                if (old->mu.try_lock()) {  // nobody is enqueueing with it, and nobody can get it while pool_mu is held
+                    old->release();        // hipFree waits for the work that still uses the buffers
+                    old->mu.unlock();
+                    delete old;
+                    jt = h->stream_ws.erase(jt);
+                } else {
+                    ++jt;
+                }
+            }
+        }
+        w = new (std::nothrow) Workspace();
+        if (w) h->stream_ws[stream] = w;
+    }
+    if (w) held = std::unique_lock<std::mutex>(w->mu);
     return w;
 }
 
@@ -400,7 +446,8 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     const int64_t n_groups = n_super * (kSuperRows / GR);  // group maxima per query (tail groups hold -inf)
     const int Gsmall = max_groups_for_dim(h);
     // batches beyond what fits LDS whole go through the k-chunked large-batch pass, 128 or 256 queries at a time
-    const bool big = B > 16 * Gsmall && h->KT % 4 == 0 && std::getenv("HBMRAG_NO_BIGQ") == nullptr;
+    static const bool no_bigq = std::getenv("HBMRAG_NO_BIGQ") != nullptr;
+    const bool big = B > 16 * Gsmall && h->KT % 4 == 0 && !no_bigq;
     const bool big256 = big && B > 128 && qreg_supported(h);   // 256 queries per pass, queries in registers
     const int Gmax = big256 ? 16 : big ? 8 : Gsmall;
     const int chunk_q = 16 * Gmax;
@@ -510,7 +557,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         HIP_TRY(h, ws->pq_idx.ensure((size_t)B * stride * 4));
         HIP_TRY(h, ws->pq_w.ensure((size_t)B * stride * 4));
         hipLaunchKernelGGL(sparse_query_prep_kernel, dim3(B), dim3(256), 0, s, d_qptr, d_qidx, d_qval,
-                           h->max_sparse_abs, stride, ws->qscale.as<float>(), ws->qeps.as<float>(),
+                           h->max_sparse_abs, stride, (int)h->sparse_dim, ws->qscale.as<float>(), ws->qeps.as<float>(),
                            ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>());
         HIP_TRY(h, hipGetLastError());
     }
@@ -651,62 +698,101 @@ int add_dense_impl(hr_index* h, const SRC* rows, int64_t n, bool src_on_device, 
     return HR_OK;
 }
 
+// One CSR batch as hr_add_sparse and hr_load accept it: indptr monotone, indices in [0, sparse_dim) and strictly
+// ascending inside a row, values finite and within the fp16 posting range.  *batch_max receives max |value|.
+int validate_csr(const hr_index* h, const int64_t* indptr, const int32_t* indices, const float* values, int64_t n,
+                 float* batch_max) {
+    float mx = 0.f;
+    for (int64_t r = 0; r < n; ++r) {
+        if (indptr[r + 1] < indptr[r]) return fail(h, HR_EINVAL, "indptr not monotone at row %lld", (long long)r);
+        int32_t prev = -1;
+        for (int64_t e = indptr[r]; e < indptr[r + 1]; ++e) {
+            const int32_t t = indices[e];
+            if (t < 0 || t >= h->sparse_dim)
+                return fail(h, HR_EINVAL, "sparse index %d out of range [0,%lld) in row %lld", t, (long long)h->sparse_dim, (long long)r);
+            if (t <= prev) return fail(h, HR_EINVAL, "sparse indices must be strictly ascending (row %lld)", (long long)r);
+            if (!std::isfinite(values[e])) return fail(h, HR_EINVAL, "non-finite sparse value in row %lld", (long long)r);
+            if (std::fabs(values[e]) > 60000.f)
+                return fail(h, HR_ELIMIT, "sparse weight %g in row %lld exceeds the fp16 posting range", (double)values[e], (long long)r);
+            mx = std::max(mx, std::fabs(values[e]));
+            prev = t;
+        }
+    }
+    *batch_max = mx;
+    return HR_OK;
+}
+
+// Bring the device-side sparse shard up to date with the rows staged since the last call.
+// The staged CSR rows are appended to the device CSR (kept for the canonical refine); the range-major postings are
+// rebuilt only from the range that holds the first new doc onwards — earlier ranges' posting blocks and offset rows
+// stay where they are — so a flush after a small append costs O(batch + one range), not O(corpus), and the host
+// keeps no copy of the corpus (reference indexing.py:377-431: insert + flush per index_chunks call).
 int build_sparse(hr_index* h) {
     hipStream_t s = h->ingest_stream;
-    const int64_t n = h->n_sparse;
-    const int64_t nnz = (int64_t)h->h_idx.size();
+    const int64_t n = h->n_sparse, n0 = h->n_sparse_built;
     const int64_t V1 = h->sparse_dim + 1;
-    h->n_ranges = (n + kRangeDocs - 1) / kRangeDocs;
-    if (n == 0) {
-        h->n_sparse_built = 0;
-        return HR_OK;
+    if (n == n0) return HR_OK;
+    const int64_t new_nnz = (int64_t)h->pend_idx.size();
+    const int64_t nnz = h->nnz_built + new_nnz;
+    // 1. append the staged rows to the device CSR
+    HIP_TRY(h, h->s_indptr.grow((size_t)(n + 1) * 8, (size_t)(n0 + 1) * 8, s));
+    HIP_TRY(h, h->s_idx.grow((size_t)std::max<int64_t>(nnz, 1) * 4, (size_t)h->nnz_built * 4, s));
+    HIP_TRY(h, h->s_val.grow((size_t)std::max<int64_t>(nnz, 1) * 4, (size_t)h->nnz_built * 4, s));
+    for (int64_t& v : h->pend_indptr) v += h->nnz_built;  // absolute entry numbers
+    HIP_TRY(h, hipMemcpyAsync(h->s_indptr.as<int64_t>() + n0, h->pend_indptr.data(), (size_t)(n - n0 + 1) * 8,
+                              hipMemcpyHostToDevice, s));
+    if (new_nnz) {
+        HIP_TRY(h, hipMemcpyAsync(h->s_idx.as<int32_t>() + h->nnz_built, h->pend_idx.data(), (size_t)new_nnz * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipMemcpyAsync(h->s_val.as<float>() + h->nnz_built, h->pend_val.data(), (size_t)new_nnz * 4, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(h, h->s_indptr.ensure((size_t)(n + 1) * 8));
-    HIP_TRY(h, h->s_idx.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
-    HIP_TRY(h, h->s_val.ensure((size_t)std::max<int64_t>(nnz, 1) * 4));
-    HIP_TRY(h, hipMemcpyAsync(h->s_indptr.p, h->h_indptr.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, s));
-    if (nnz) {
-        HIP_TRY(h, hipMemcpyAsync(h->s_idx.p, h->h_idx.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(h, hipMemcpyAsync(h->s_val.p, h->h_val.data(), (size_t)nnz * 4, hipMemcpyHostToDevice, s));
-    }
-    const size_t off_bytes = (size_t)h->n_ranges * V1 * 4;
-    HIP_TRY(h, h->rt_off.ensure(off_bytes));
-    HIP_TRY(h, h->range_base.ensure((size_t)(h->n_ranges + 1) * 8));
-    HIP_TRY(h, hipMemsetAsync(h->rt_off.p, 0, off_bytes, s));
-    const unsigned doc_blocks = (unsigned)((n + 255) / 256);
+    HIP_TRY(h, hipStreamSynchronize(s));  // the staging vectors are released below
+    std::vector<int64_t>{0}.swap(h->pend_indptr);
+    std::vector<int32_t>().swap(h->pend_idx);
+    std::vector<float>().swap(h->pend_val);
+    // 2. rebuild the posting blocks of ranges r_d .. n_ranges-1
+    const int64_t r_d = n0 / kRangeDocs;          // range of the first new doc
+    const int64_t doc0 = r_d * kRangeDocs;
+    const int64_t n_ranges = (n + kRangeDocs - 1) / kRangeDocs;
+    const int64_t dirty = n_ranges - r_d;
+    HIP_TRY(h, h->rt_off.grow((size_t)n_ranges * V1 * 4, (size_t)r_d * V1 * 4, s));
+    HIP_TRY(h, hipMemsetAsync(h->rt_off.as<unsigned int>() + r_d * V1, 0, (size_t)dirty * V1 * 4, s));
+    const unsigned doc_blocks = (unsigned)((n - doc0 + 255) / 256);
     hipLaunchKernelGGL(sparse_count_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
-                       h->s_idx.as<int32_t>(), n, V1, h->rt_off.as<unsigned int>());
+                       h->s_idx.as<int32_t>(), doc0, n, V1, h->rt_off.as<unsigned int>());
     HIP_TRY(h, hipGetLastError());
     struct Scratch {  // released on every return path
         DevBuf totals, cursor;
         ~Scratch() { totals.release(); cursor.release(); }
     } tmp;
-    HIP_TRY(h, tmp.totals.ensure((size_t)h->n_ranges * 8));
-    hipLaunchKernelGGL(sparse_scan_offsets_kernel, dim3((unsigned)h->n_ranges), dim3(1024), 0, s,
-                       h->rt_off.as<unsigned int>(), V1, tmp.totals.as<unsigned long long>());
+    HIP_TRY(h, tmp.totals.ensure((size_t)dirty * 8));
+    hipLaunchKernelGGL(sparse_scan_offsets_kernel, dim3((unsigned)dirty), dim3(1024), 0, s,
+                       h->rt_off.as<unsigned int>(), V1, r_d, tmp.totals.as<unsigned long long>());
     HIP_TRY(h, hipGetLastError());
-    std::vector<unsigned long long> ht(h->n_ranges);
-    HIP_TRY(h, hipMemcpyAsync(ht.data(), tmp.totals.p, (size_t)h->n_ranges * 8, hipMemcpyDeviceToHost, s));
+    std::vector<unsigned long long> ht(dirty);
+    HIP_TRY(h, hipMemcpyAsync(ht.data(), tmp.totals.p, (size_t)dirty * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    std::vector<int64_t> base(h->n_ranges + 1, 0);
-    for (int64_t r = 0; r < h->n_ranges; ++r) base[r + 1] = base[r] + (int64_t)ht[r];
-    // runs are padded to 4 postings (filler postings): at most 3 more per (range, term) that occurs
-    HIP_TRY(h, h->post.ensure((size_t)base[h->n_ranges] * 4 + 64));  // + slack: the scan fetches 16 bytes at a time
-    HIP_TRY(h, hipMemcpyAsync(h->range_base.p, base.data(), base.size() * 8, hipMemcpyHostToDevice, s));
-    hipError_t e = tmp.cursor.ensure(off_bytes);
-    if (e != hipSuccess) return fail(h, HR_ENOMEM, "sparse build cursor: %s", hipGetErrorString(e));
-    HIP_TRY(h, hipMemcpyAsync(tmp.cursor.p, h->rt_off.p, off_bytes, hipMemcpyDeviceToDevice, s));
+    h->h_range_base.resize(n_ranges + 1);
+    for (int64_t r = r_d; r < n_ranges; ++r) h->h_range_base[r + 1] = h->h_range_base[r] + (int64_t)ht[r - r_d];
+    // runs are padded to 4 postings (filler postings); + slack: the scan fetches 16 bytes at a time
+    HIP_TRY(h, h->post.grow((size_t)h->h_range_base[n_ranges] * 4 + 64, (size_t)h->h_range_base[r_d] * 4, s));
+    HIP_TRY(h, h->range_base.grow((size_t)(n_ranges + 1) * 8, 0, s));
+    HIP_TRY(h, hipMemcpyAsync(h->range_base.p, h->h_range_base.data(), (size_t)(n_ranges + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, tmp.cursor.ensure((size_t)dirty * V1 * 4));
+    HIP_TRY(h, hipMemcpyAsync(tmp.cursor.p, h->rt_off.as<unsigned int>() + r_d * V1, (size_t)dirty * V1 * 4,
+                              hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(sparse_fill_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
-                       h->s_idx.as<int32_t>(), h->s_val.as<float>(), n, V1, tmp.cursor.as<unsigned int>(),
+                       h->s_idx.as<int32_t>(), h->s_val.as<float>(), doc0, n, V1, tmp.cursor.as<unsigned int>(),
                        h->range_base.as<int64_t>(), h->post.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());
-    const int64_t pairs = h->n_ranges * h->sparse_dim;
+    const int64_t pairs = dirty * h->sparse_dim;
     hipLaunchKernelGGL(sparse_pad_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
-                       h->rt_off.as<unsigned int>(), tmp.cursor.as<unsigned int>(), V1, h->n_ranges,
+                       h->rt_off.as<unsigned int>(), tmp.cursor.as<unsigned int>(), V1, r_d, n_ranges,
                        h->range_base.as<int64_t>(), h->post.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(s));
+    h->n_ranges = n_ranges;
     h->n_sparse_built = n;
+    h->nnz_built = nnz;
     return HR_OK;
 }
 
@@ -859,30 +945,16 @@ int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indices, co
     const int64_t nnz = indptr[n] - indptr[0];
     if (nnz < 0 || (nnz > 0 && (!indices || !values))) return fail(h, HR_EINVAL, "bad indices/values");
     float batch_max = 0.f;
-    for (int64_t r = 0; r < n; ++r) {
-        if (indptr[r + 1] < indptr[r]) return fail(h, HR_EINVAL, "indptr not monotone at row %lld", (long long)r);
-        int32_t prev = -1;
-        for (int64_t e = indptr[r]; e < indptr[r + 1]; ++e) {
-            const int32_t t = indices[e];
-            if (t < 0 || t >= h->sparse_dim)
-                return fail(h, HR_EINVAL, "sparse index %d out of range [0,%lld) in row %lld", t, (long long)h->sparse_dim, (long long)r);
-            if (t <= prev) return fail(h, HR_EINVAL, "sparse indices must be strictly ascending (row %lld)", (long long)r);
-            if (!std::isfinite(values[e])) return fail(h, HR_EINVAL, "non-finite sparse value in row %lld", (long long)r);
-            if (std::fabs(values[e]) > 60000.f)
-                return fail(h, HR_ELIMIT, "sparse weight %g in row %lld exceeds the fp16 posting range", (double)values[e], (long long)r);
-            batch_max = std::max(batch_max, std::fabs(values[e]));
-            prev = t;
-        }
-    }
+    HR_TRY(validate_csr(h, indptr, indices, values, n, &batch_max));
     std::unique_lock<std::shared_mutex> lk(h->rw);
     if (h->n_sparse + n > (1ll << 31) - 64) return fail(h, HR_ELIMIT, "too many sparse rows");
-    try {
-        const int64_t base = h->h_indptr.back() - indptr[0];
-        h->h_indptr.reserve(h->h_indptr.size() + n);
-        for (int64_t r = 1; r <= n; ++r) h->h_indptr.push_back(indptr[r] + base);
-        h->h_idx.insert(h->h_idx.end(), indices + indptr[0], indices + indptr[n]);
-        h->h_val.insert(h->h_val.end(), values + indptr[0], values + indptr[n]);
-    } catch (const std::bad_alloc&) {
+    try {  // staged on the host only until the next hr_finalize uploads them
+        const int64_t base = h->pend_indptr.back() - indptr[0];
+        h->pend_indptr.reserve(h->pend_indptr.size() + n);
+        for (int64_t r = 1; r <= n; ++r) h->pend_indptr.push_back(indptr[r] + base);
+        h->pend_idx.insert(h->pend_idx.end(), indices + indptr[0], indices + indptr[n]);
+        h->pend_val.insert(h->pend_val.end(), values + indptr[0], values + indptr[n]);
+    } catch (const std::exception&) {
         return fail(h, HR_ENOMEM, "out of host memory staging sparse rows");
     }
     h->n_sparse += n;
@@ -926,8 +998,9 @@ struct SnapHeader {
     int32_t version, dtype, metric, KT;
     int64_t dim, sparse_dim, n_rows, cap_rows, n_sparse, nnz, row_offset;
     float max_row_norm, max_sparse_abs;
+    int64_t file_bytes;  // header + every section: a truncated file is refused before anything is uploaded
 };
-const char kSnapMagic[8] = {'H', 'B', 'M', 'R', 'A', 'G', '0', '1'};
+const char kSnapMagic[8] = {'H', 'B', 'M', 'R', 'A', 'G', '0', '2'};
 
 struct File {
     FILE* f = nullptr;
@@ -953,6 +1026,31 @@ int stream_in(hr_index* h, FILE* f, void* dptr, size_t bytes) {
     }
     return HR_OK;
 }
+
+int save_to(hr_index* h, FILE* f) {
+    SnapHeader hd{};
+    std::memcpy(hd.magic, kSnapMagic, 8);
+    hd.version = 2; hd.dtype = h->dtype; hd.metric = h->metric; hd.KT = h->KT;
+    hd.dim = h->dim; hd.sparse_dim = h->sparse_dim; hd.n_rows = h->n_rows;
+    hd.cap_rows = h->dim ? round_up(std::max<int64_t>(h->n_rows, 1), kSuperRows) : 0;
+    hd.n_sparse = h->n_sparse; hd.nnz = h->nnz_built; hd.row_offset = h->row_offset;
+    hd.max_row_norm = h->max_row_norm; hd.max_sparse_abs = h->max_sparse_abs;
+    const bool dense = h->dim > 0 && h->n_rows > 0;
+    hd.file_bytes = (int64_t)sizeof hd + (dense ? (int64_t)tile_bytes_for_rows(h, hd.cap_rows) + hd.cap_rows * 12 : 0) +
+                    (h->n_sparse > 0 ? (h->n_sparse + 1) * 8 + hd.nnz * 8 : 0);
+    if (fwrite(&hd, sizeof hd, 1, f) != 1) return fail(h, HR_EINVAL, "snapshot write failed");
+    if (dense) {
+        HR_TRY(stream_out(h, f, h->tiles.p, tile_bytes_for_rows(h, hd.cap_rows)));
+        HR_TRY(stream_out(h, f, h->scale.p, (size_t)hd.cap_rows * 4));
+        HR_TRY(stream_out(h, f, h->norm2.p, (size_t)hd.cap_rows * 8));
+    }
+    if (h->n_sparse > 0) {  // the CSR is read back from the device: the host keeps no copy of it
+        HR_TRY(stream_out(h, f, h->s_indptr.p, (size_t)(h->n_sparse + 1) * 8));
+        HR_TRY(stream_out(h, f, h->s_idx.p, (size_t)hd.nnz * 4));
+        HR_TRY(stream_out(h, f, h->s_val.p, (size_t)hd.nnz * 4));
+    }
+    return HR_OK;
+}
 }  // namespace
 
 int hr_save(hr_index* h, const char* path) {
@@ -961,42 +1059,42 @@ int hr_save(hr_index* h, const char* path) {
     std::unique_lock<std::shared_mutex> lk(h->rw);
     DeviceGuard dg(h->device);
     HIP_TRY(h, hipDeviceSynchronize());
-    File file;
-    file.f = fopen(path, "wb");
-    if (!file.f) return fail(h, HR_EINVAL, "cannot open %s for writing", path);
-    SnapHeader hd{};
-    std::memcpy(hd.magic, kSnapMagic, 8);
-    hd.version = 1; hd.dtype = h->dtype; hd.metric = h->metric; hd.KT = h->KT;
-    hd.dim = h->dim; hd.sparse_dim = h->sparse_dim; hd.n_rows = h->n_rows;
-    hd.cap_rows = h->dim ? round_up(std::max<int64_t>(h->n_rows, 1), kSuperRows) : 0;
-    hd.n_sparse = h->n_sparse; hd.nnz = (int64_t)h->h_idx.size(); hd.row_offset = h->row_offset;
-    hd.max_row_norm = h->max_row_norm; hd.max_sparse_abs = h->max_sparse_abs;
-    if (fwrite(&hd, sizeof hd, 1, file.f) != 1) return fail(h, HR_EINVAL, "snapshot write failed");
-    if (h->dim > 0 && h->n_rows > 0) {
-        HR_TRY(stream_out(h, file.f, h->tiles.p, tile_bytes_for_rows(h, hd.cap_rows)));
-        HR_TRY(stream_out(h, file.f, h->scale.p, (size_t)hd.cap_rows * 4));
-        HR_TRY(stream_out(h, file.f, h->norm2.p, (size_t)hd.cap_rows * 8));
+    // written beside the target and renamed once complete: a full disk or a crash leaves the old snapshot intact
+    std::string tmp_path;
+    try {
+        tmp_path = std::string(path) + ".tmp";
+    } catch (const std::exception&) {
+        return fail(h, HR_ENOMEM, "out of host memory");
     }
-    if (h->n_sparse > 0) {
-        const bool ok = fwrite(h->h_indptr.data(), 8, (size_t)h->n_sparse + 1, file.f) == (size_t)h->n_sparse + 1 &&
-                        fwrite(h->h_idx.data(), 4, (size_t)hd.nnz, file.f) == (size_t)hd.nnz &&
-                        fwrite(h->h_val.data(), 4, (size_t)hd.nnz, file.f) == (size_t)hd.nnz;
-        if (!ok) return fail(h, HR_EINVAL, "snapshot write failed");
+    int rc;
+    {
+        File file;
+        file.f = fopen(tmp_path.c_str(), "wb");
+        if (!file.f) return fail(h, HR_EINVAL, "cannot open %s for writing", tmp_path.c_str());
+        rc = save_to(h, file.f);
+        if (rc == HR_OK && fflush(file.f) != 0) rc = fail(h, HR_EINVAL, "snapshot write failed (flush)");
+        FILE* f = file.f;
+        file.f = nullptr;
+        if (fclose(f) != 0 && rc == HR_OK) rc = fail(h, HR_EINVAL, "snapshot write failed (close)");
     }
-    return HR_OK;
+    if (rc == HR_OK && std::rename(tmp_path.c_str(), path) != 0) rc = fail(h, HR_EINVAL, "cannot move snapshot into place at %s", path);
+    if (rc != HR_OK) (void)std::remove(tmp_path.c_str());
+    return rc;
 }
 
-int hr_load(const char* path, int device, hr_index** out) {
-    if (!path || !out) return fail(nullptr, HR_EINVAL, "null argument");
-    *out = nullptr;
+static int load_impl(const char* path, int device, hr_index** out) {
     File file;
     file.f = fopen(path, "rb");
     if (!file.f) return fail(nullptr, HR_EINVAL, "cannot open %s", path);
     SnapHeader hd{};
-    if (fread(&hd, sizeof hd, 1, file.f) != 1 || std::memcmp(hd.magic, kSnapMagic, 8) != 0 || hd.version != 1)
-        return fail(nullptr, HR_EINVAL, "%s is not a libhbmrag snapshot (version 1)", path);
-    if (hd.n_rows < 0 || hd.n_sparse < 0 || hd.nnz < 0 || hd.cap_rows < hd.n_rows)
+    if (fread(&hd, sizeof hd, 1, file.f) != 1 || std::memcmp(hd.magic, kSnapMagic, 8) != 0 || hd.version != 2)
+        return fail(nullptr, HR_EINVAL, "%s is not a libhbmrag snapshot (version 2)", path);
+    if (hd.n_rows < 0 || hd.n_sparse < 0 || hd.nnz < 0 || hd.cap_rows < hd.n_rows || hd.n_sparse > (1ll << 31) - 64 ||
+        hd.nnz > (1ll << 40) || !(hd.max_sparse_abs >= 0.f) || !(hd.max_row_norm >= 0.f))
         return fail(nullptr, HR_EINVAL, "corrupt snapshot header");
+    if (fseek(file.f, 0, SEEK_END) != 0 || (int64_t)ftell(file.f) != hd.file_bytes || fseek(file.f, (long)sizeof hd, SEEK_SET) != 0)
+        return fail(nullptr, HR_EINVAL, "snapshot truncated or padded: %s does not hold the %lld bytes its header announces", path,
+                    (long long)hd.file_bytes);
     hr_index* h = nullptr;
     HR_TRY(hr_create(device, hd.dim, hd.dtype, hd.metric, hd.sparse_dim, &h));
     struct Guard { hr_index* h; bool keep = false; ~Guard() { if (!keep) hr_destroy(h); } } guard{h};
@@ -1004,6 +1102,7 @@ int hr_load(const char* path, int device, hr_index** out) {
     h->row_offset = hd.row_offset;
     DeviceGuard dg(device);
     if (hd.dim > 0 && hd.n_rows > 0) {
+        if (hd.cap_rows != round_up(hd.n_rows, kSuperRows)) return fail(nullptr, HR_EINVAL, "corrupt snapshot header (row capacity)");
         HR_TRY(hr_reserve(h, hd.cap_rows));
         int rc = stream_in(h, file.f, h->tiles.p, tile_bytes_for_rows(h, hd.cap_rows));
         if (rc == HR_OK) rc = stream_in(h, file.f, h->scale.p, (size_t)hd.cap_rows * 4);
@@ -1017,25 +1116,46 @@ int hr_load(const char* path, int device, hr_index** out) {
             return fail(nullptr, HR_EHIP, "snapshot upload failed");
     }
     if (hd.n_sparse > 0) {
-        try {
-            h->h_indptr.resize((size_t)hd.n_sparse + 1);
-            h->h_idx.resize((size_t)hd.nnz);
-            h->h_val.resize((size_t)hd.nnz);
-        } catch (const std::bad_alloc&) {
-            return fail(nullptr, HR_ENOMEM, "out of host memory loading snapshot");
-        }
-        const bool ok = fread(h->h_indptr.data(), 8, (size_t)hd.n_sparse + 1, file.f) == (size_t)hd.n_sparse + 1 &&
-                        fread(h->h_idx.data(), 4, (size_t)hd.nnz, file.f) == (size_t)hd.nnz &&
-                        fread(h->h_val.data(), 4, (size_t)hd.nnz, file.f) == (size_t)hd.nnz;
-        if (!ok || h->h_indptr.front() != 0 || h->h_indptr.back() != hd.nnz)
+        if (hd.sparse_dim <= 0) return fail(nullptr, HR_EINVAL, "corrupt snapshot header (sparse rows without a sparse collection)");
+        // the file is not trusted: the CSR goes through the same checks as hr_add_sparse before any kernel indexes with it
+        std::vector<int64_t> ptr((size_t)hd.n_sparse + 1);
+        std::vector<int32_t> idx((size_t)hd.nnz);
+        std::vector<float> val((size_t)hd.nnz);
+        const bool ok = fread(ptr.data(), 8, ptr.size(), file.f) == ptr.size() &&
+                        fread(idx.data(), 4, idx.size(), file.f) == idx.size() &&
+                        fread(val.data(), 4, val.size(), file.f) == val.size();
+        if (!ok || ptr.front() != 0 || ptr.back() != hd.nnz)
             return fail(nullptr, HR_EINVAL, "snapshot truncated or corrupt (sparse section)");
-        h->n_sparse = hd.n_sparse;
-        h->max_sparse_abs = hd.max_sparse_abs;
+        for (int64_t r = 0; r < hd.n_sparse; ++r)
+            if (ptr[r + 1] < ptr[r] || ptr[r + 1] > hd.nnz) return fail(nullptr, HR_EINVAL, "snapshot corrupt (sparse row pointers)");
+        int rc = hr_add_sparse(h, ptr.data(), idx.data(), val.data(), hd.n_sparse);  // validates; recomputes max |weight|
+        if (rc != HR_OK) return fail(nullptr, rc, "snapshot corrupt (sparse section): %s", hr_last_error(h));
     }
     int rc = hr_finalize(h);
     if (rc != HR_OK) return fail(nullptr, rc, "%s", hr_last_error(h));
     guard.keep = true;
     *out = h;
+    return HR_OK;
+}
+
+int hr_load(const char* path, int device, hr_index** out) {
+    if (!path || !out) return fail(nullptr, HR_EINVAL, "null argument");
+    *out = nullptr;
+    try {
+        return load_impl(path, device, out);
+    } catch (const std::bad_alloc&) {
+        return fail(nullptr, HR_ENOMEM, "out of host memory loading snapshot");
+    } catch (const std::exception& e) {  // e.g. std::length_error from an absurd size in a damaged header
+        return fail(nullptr, HR_EINVAL, "snapshot refused: %s", e.what());
+    }
+}
+
+int hr_get_info(const hr_index* h, int64_t* dim, int32_t* dtype, int32_t* metric, int64_t* sparse_dim) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (dim) *dim = h->dim;
+    if (dtype) *dtype = h->dtype;
+    if (metric) *metric = h->metric;
+    if (sparse_dim) *sparse_dim = h->sparse_dim;
     return HR_OK;
 }
 
@@ -1064,7 +1184,8 @@ int hr_search_dense_dev(hr_index* h, const float* d_q, int B, int k, const uint8
     DeviceGuard dg(h->device);
     hipStream_t s = (hipStream_t)stream;
     if (h->n_rows == 0) return fill_empty(h, s, B, k, d_ids, d_scores, d_flags);
-    Workspace* ws = ws_for_stream(h, stream);
+    std::unique_lock<std::mutex> ws_held;
+    Workspace* ws = ws_for_stream(h, stream, ws_held);
     if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
     return dense_search_enqueue(h, ws, s, d_q, B, k, d_rowmask, d_ids, d_scores, d_flags, candidate_groups_for_k(k));
 }
@@ -1080,7 +1201,8 @@ int hr_search_sparse_dev(hr_index* h, const int64_t* d_q_indptr, const int32_t* 
     DeviceGuard dg(h->device);
     hipStream_t s = (hipStream_t)stream;
     if (h->n_sparse == 0) return fill_empty(h, s, B, k, d_ids, d_scores, d_flags);
-    Workspace* ws = ws_for_stream(h, stream);
+    std::unique_lock<std::mutex> ws_held;
+    Workspace* ws = ws_for_stream(h, stream, ws_held);
     if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
     return sparse_search_enqueue(h, ws, s, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, d_ids, d_scores,
                                  d_flags, candidate_groups_for_k(k));
@@ -1100,7 +1222,8 @@ int hr_search_hybrid_dev(hr_index* h, const float* d_q, const int64_t* d_q_indpt
     int64_t* s_ids = d_ids + (size_t)B * k;
     float* s_scores = d_scores + (size_t)B * k;
     int32_t* s_flags = d_flags ? d_flags + B : nullptr;
-    Workspace* ws = ws_for_stream(h, stream);
+    std::unique_lock<std::mutex> ws_held;
+    Workspace* ws = ws_for_stream(h, stream, ws_held);
     if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
     if (!ws->side) {
         HIP_TRY(h, hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
@@ -1153,6 +1276,7 @@ int hr_hybrid_scan_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr,
     DeviceGuard dg(h->device);
     Workspace *wd, *wsp;
     HR_TRY(slot_workspaces(h, slot, &wd, &wsp));
+    std::lock_guard<std::mutex> slot_held(wd->mu);
     hipStream_t s = (hipStream_t)stream;
     const int C = candidate_groups_for_k(k);
     if (h->n_rows > 0)
@@ -1173,6 +1297,7 @@ int hr_hybrid_finish_dev(hr_index* h, const float* d_q, const int64_t* d_q_indpt
     DeviceGuard dg(h->device);
     Workspace *wd, *wsp;
     HR_TRY(slot_workspaces(h, slot, &wd, &wsp));
+    std::lock_guard<std::mutex> slot_held(wd->mu);
     hipStream_t s = (hipStream_t)stream;
     const int C = candidate_groups_for_k(k);
     int64_t* s_ids = d_ids + (size_t)B * k;

@@ -16,9 +16,11 @@ constexpr int kScanTermChunk = 256;                   // query terms staged per 
 // ---- build: CSR (doc-major) -> range-major postings ---------------------------
 // rt_off[range][t] counts, then (after the per-range exclusive scan) offsets of
 // term t's run inside the range's posting block.
+// All three build kernels work on docs [doc0, n_docs): an append rebuilds only the ranges from the one that holds
+// the first new doc onwards (doc0 = that range's first doc).
 __global__ void sparse_count_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
-                                    int64_t n_docs, int64_t V1, unsigned int* __restrict__ rt_off) {
-    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                                    int64_t doc0, int64_t n_docs, int64_t V1, unsigned int* __restrict__ rt_off) {
+    int64_t d = doc0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_docs) return;
     unsigned int* row = rt_off + (d / kRangeDocs) * V1;
     for (int64_t e = indptr[d]; e < indptr[d + 1]; ++e) atomicAdd(&row[idx[e]], 1u);
@@ -28,10 +30,11 @@ __global__ void sparse_count_kernel(const int64_t* __restrict__ indptr, const in
 // 4 postings (the scan fetches 16 bytes per lane and applies all four without a validity test; the
 // round-up slots hold filler postings, see sparse_pad_kernel); slot V gets the total.
 __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int* __restrict__ rt_off, int64_t V1,
+                                                                   int64_t range0,
                                                                    unsigned long long* __restrict__ range_total) {
     __shared__ unsigned int wsum[16];
     __shared__ unsigned int carry;
-    unsigned int* row = rt_off + (int64_t)blockIdx.x * V1;
+    unsigned int* row = rt_off + (range0 + (int64_t)blockIdx.x) * V1;
     const int64_t V = V1 - 1;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -88,14 +91,15 @@ __device__ inline float posting_weight(uint32_t p) {
 // Scatter postings.  cursor = copy of rt_off; order inside a run follows the
 // atomics (the scan's sums are order-independent up to fp32 rounding, which
 // the refine step makes irrelevant).
+// cursor holds the rows of ranges >= range0 only.
 __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
-                                   const float* __restrict__ val, int64_t n_docs, int64_t V1,
+                                   const float* __restrict__ val, int64_t doc0, int64_t n_docs, int64_t V1,
                                    unsigned int* __restrict__ cursor, const int64_t* __restrict__ range_base,
                                    uint32_t* __restrict__ post) {
-    int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t d = doc0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_docs) return;
     const int64_t range = d / kRangeDocs;
-    unsigned int* cur = cursor + range * V1;
+    unsigned int* cur = cursor + (range - doc0 / kRangeDocs) * V1;
     const int64_t base = range_base[range];
     const uint16_t local = (uint16_t)(d - range * kRangeDocs);
     for (int64_t e = indptr[d]; e < indptr[d + 1]; ++e) {
@@ -108,14 +112,14 @@ __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int
 // accumulators' pad words, which nobody reads.  cursor = where sparse_fill_kernel stopped.
 __device__ __host__ inline uint32_t filler_posting(unsigned int k) { return (uint32_t)(kAccSlice * (k & 511u) + 32u); }
 __global__ void sparse_pad_kernel(const unsigned int* __restrict__ rt_off, const unsigned int* __restrict__ cursor,
-                                  int64_t V1, int64_t n_ranges, const int64_t* __restrict__ range_base,
+                                  int64_t V1, int64_t range0, int64_t n_ranges, const int64_t* __restrict__ range_base,
                                   uint32_t* __restrict__ post) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (range, term)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (range - range0, term)
     const int64_t V = V1 - 1;
-    if (i >= n_ranges * V) return;
-    const int64_t range = i / V, t = i - range * V;
+    if (i >= (n_ranges - range0) * V) return;
+    const int64_t rel = i / V, t = i - rel * V, range = range0 + rel;
     const unsigned int end = rt_off[range * V1 + t + 1];
-    for (unsigned int p = cursor[range * V1 + t]; p < end; ++p) post[range_base[range] + p] = filler_posting((unsigned int)t);
+    for (unsigned int p = cursor[rel * V1 + t]; p < end; ++p) post[range_base[range] + p] = filler_posting((unsigned int)t);
 }
 
 // ---- query prep: fixed-point scale per query -------------------------------------
@@ -133,7 +137,7 @@ __global__ void sparse_pad_kernel(const unsigned int* __restrict__ rt_off, const
 __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* __restrict__ q_indptr,
                                                                 const int32_t* __restrict__ q_idx,
                                                                 const float* __restrict__ q_val, float max_doc_w,
-                                                                int stride, float* __restrict__ q_scale,
+                                                                int stride, int sparse_dim, float* __restrict__ q_scale,
                                                                 float* __restrict__ q_eps, int32_t* __restrict__ pq_n,
                                                                 int32_t* __restrict__ pq_idx,
                                                                 float* __restrict__ pq_w) {
@@ -163,7 +167,9 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
     }
     for (int i = tid; i < stride; i += 256) {
         const bool in = t0 + i < t1;
-        pq_idx[(int64_t)qi * stride + i] = in ? q_idx[t0 + i] : 0;
+        // the scan indexes the run-bound rows with these: an index outside [0, sparse_dim) (only a caller that bypasses
+        // pack_sparse_queries can produce one) is clamped instead of being allowed to read out of bounds
+        pq_idx[(int64_t)qi * stride + i] = in ? min(max(q_idx[t0 + i], 0), sparse_dim - 1) : 0;
         pq_w[(int64_t)qi * stride + i] = in ? q_val[t0 + i] * scale : 0.f;
     }
 }

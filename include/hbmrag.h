@@ -26,8 +26,10 @@
  *     with id -1 / score 0 when fewer than k rows qualify;
  *   - row ids are int64 "global row numbers": local row + the shard's row
  *     offset (hr_set_row_offset), so per-shard lists can be merged across GPUs;
- *   - search calls are thread-safe against each other (each takes a private
- *     workspace + stream from a pool); add/finalize take an exclusive lock.
+ *   - search calls are thread-safe against each other: a host-form call takes a
+ *     private workspace + stream from a pool; `*_dev` calls on the same stream
+ *     share one workspace and are serialised while they enqueue (their kernels
+ *     then run in stream order); add/finalize take an exclusive lock.
  *
  * Result semantics (what the oracle in oracle/ restates bit-for-bit)
  *   dense  : score32 = (float) S, S computed in fp64 by a k-ordered sequential
@@ -112,11 +114,17 @@ HR_API int hr_add_sparse(hr_index* h, const int64_t* indptr, const int32_t* indi
 HR_API int hr_finalize(hr_index* h);
 
 /* Shard snapshot (checkpoint / resume; the reference relies on Milvus'
- * persistence, indexing.py:185-188, :430-431).  One file: header, dense tiles +
- * norms exactly as they sit in HBM, and the sparse CSR; the range-major postings
- * are rebuilt on load.  hr_load creates a finalized handle on `device`. */
+ * persistence, indexing.py:185-188, :430-431).  One file: header (with the file's
+ * total size), dense tiles + norms exactly as they sit in HBM, and the sparse CSR
+ * (read back from the device); the range-major postings are rebuilt on load.
+ * hr_save writes `path`.tmp and renames it over `path` once complete.  hr_load
+ * does not trust the file: sizes are checked against the header and the CSR goes
+ * through hr_add_sparse's checks; it creates a finalized handle on `device`. */
 HR_API int hr_save(hr_index* h, const char* path);
 HR_API int hr_load(const char* path, int device, hr_index** out);
+/* What a handle (e.g. one returned by hr_load) holds: dimension, storage dtype, metric, sparse dimension.
+ * Any out pointer may be NULL. */
+HR_API int hr_get_info(const hr_index* h, int64_t* dim, int32_t* dtype, int32_t* metric, int64_t* sparse_dim);
 
 HR_API int64_t hr_num_rows(const hr_index* h);        /* dense rows (Collection.num_entities, indexing.py:687) */
 HR_API int64_t hr_num_sparse_rows(const hr_index* h);

@@ -1,0 +1,191 @@
+"""Ingest, resume and concurrency of the shard store (reference indexing.py:377-431 inserts and flushes
+per index_chunks call): incremental sparse appends rebuild only the tail ranges, the host keeps no copy of the corpus,
+snapshots are validated on load, `*_dev` searches that share a stream are serialised."""
+import os
+import struct
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+from advanced_rag import _native as nat
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _sparse(rng, n, V, nnz):
+    idx = np.sort(np.argpartition(rng.random((n, V)), nnz - 1, axis=1)[:, :nnz], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * nnz)).astype(np.float32)
+    return np.arange(n + 1, dtype=np.int64) * nnz, idx, val
+
+
+def test_fifty_ragged_appends_stay_bit_exact(gpu):
+    """50 appends of 1 .. 3 000 docs (several crossing the 16 384-doc range boundary), a flush after every one, and
+    a search against the oracle on the prefix after every fifth: the tail-range rebuild must leave exactly the
+    index a from-scratch build gives."""
+    rng = np.random.default_rng(17)
+    V, nnz = 700, 9
+    sizes = [int(x) for x in rng.integers(1, 3000, size=50)]
+    sizes[3], sizes[10], sizes[11] = 1, 16384 - sum(sizes[:10]) % 16384, 5  # land exactly on a boundary, then step over
+    n = sum(sizes)
+    ptr, idx, val = _sparse(rng, n, V, nnz)
+    queries = [(np.sort(rng.choice(V, 25, replace=False)).astype(np.int32), np.abs(rng.standard_normal(25)).astype(np.float32))
+               for _ in range(4)]
+    h = nat.ShardHandle(0, sparse_dim=V)
+    lo = 0
+    for i, sz in enumerate(sizes):
+        h.add_sparse(ptr[lo:lo + sz + 1], idx, val)
+        lo += sz
+        h.finalize()
+        assert h.num_sparse_rows == lo
+        if i % 5 == 4 or i == len(sizes) - 1:
+            ids, sc = h.search_sparse(queries, 30, 0.2)
+            oi, os_ = oracle.sparse_search(ptr[:lo + 1], idx, val, queries, 30, 0.2)
+            assert np.array_equal(ids, oi), i
+            assert np.array_equal(_bits(sc), _bits(os_))
+    fresh = nat.ShardHandle(0, sparse_dim=V)
+    fresh.add_sparse(ptr, idx, val)
+    fresh.finalize()
+    a, b = h.search_sparse(queries, 50, 0.0), fresh.search_sparse(queries, 50, 0.0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1]))
+    h.close()
+    fresh.close()
+
+
+def test_small_append_costs_one_range_and_host_keeps_no_corpus(gpu):
+    psutil = pytest.importorskip("psutil")
+    rng = np.random.default_rng(5)
+    V, nnz, blk = 10000, 100, 250_000
+    h = nat.ShardHandle(0, sparse_dim=V)
+    proc = psutil.Process()
+    rss0 = proc.memory_info().rss
+    t_build = 0.0
+    for b in range(8):  # 2M docs, 200M entries: 1.6 GB of CSR + 0.8 GB of postings on the device
+        ptr = np.arange(blk + 1, dtype=np.int64) * nnz
+        idx = ((np.arange(nnz, dtype=np.int32) * (V // nnz))[None, :] +
+               rng.integers(0, V // nnz, size=(blk, nnz), dtype=np.int32)).reshape(-1)
+        val = np.abs(rng.standard_normal(blk * nnz, dtype=np.float32))
+        h.add_sparse(ptr, idx, val)
+        t0 = time.perf_counter()
+        h.finalize()
+        t_build += time.perf_counter() - t0
+        del ptr, idx, val
+    rss1 = proc.memory_info().rss
+    assert rss1 - rss0 < 600e6, f"host RSS grew by {(rss1 - rss0) / 1e6:.0f} MB for a 1.6 GB CSR: the corpus must live on the device"
+    ptr, idx, val = _sparse(rng, 1000, V, nnz)
+    h.add_sparse(ptr, idx, val)
+    t0 = time.perf_counter()
+    h.finalize()
+    t_small = time.perf_counter() - t0
+    assert h.num_sparse_rows == 8 * blk + 1000
+    print(f"2M-doc build in 8 flushes: {t_build * 1e3:.0f} ms; flush after a 1 000-doc append: {t_small * 1e3:.1f} ms")
+    assert t_small < 0.1 * t_build and t_small < 0.25
+    # the appended docs are searchable: a query that is one of them finds it first
+    q = [(idx[:nnz], val[:nnz])]
+    ids, _ = h.search_sparse(q, 5, 0.0)
+    assert ids[0, 0] == 8 * blk
+    h.close()
+
+
+def test_snapshot_is_validated_on_load(gpu, tmp_path):
+    rng = np.random.default_rng(3)
+    n, d, V = 3000, 64, 500
+    X = rng.standard_normal((n, d)).astype(np.float16)
+    ptr, idx, val = _sparse(rng, n, V, 7)
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    h.add_dense(X)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    path = str(tmp_path / "s.hbmrag")
+    h.save(path)
+    assert not os.path.exists(path + ".tmp")
+    good = open(path, "rb").read()
+    q = rng.standard_normal((2, d)).astype(np.float32)
+    back = nat.ShardHandle.load(path, d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+    a, b = h.search_dense(q, 10), back.search_dense(q, 10)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1]))
+    sq = [(idx[:7], val[:7])]
+    a, b = h.search_sparse(sq, 10, 0.0), back.search_sparse(sq, 10, 0.0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1]))
+    back.close()
+    # what the caller expects is checked against what the file holds
+    for args in ((d * 2, nat.HR_F16, nat.HR_METRIC_COSINE, V), (d, nat.HR_F32, nat.HR_METRIC_COSINE, V),
+                 (d, nat.HR_F16, nat.HR_METRIC_IP, V), (d, nat.HR_F16, nat.HR_METRIC_COSINE, V + 1)):
+        with pytest.raises(ValueError):
+            nat.ShardHandle.load(path, *args)
+
+    def refused(blob, name):
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        with pytest.raises(ValueError):
+            nat.ShardHandle.load(p, d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
+
+    refused(good[:len(good) - 100], "truncated")                      # shorter than the header says
+    refused(good + b"\0" * 8, "padded")
+    refused(b"NOTASNAP" + good[8:], "magic")
+    sparse_at = len(good) - (n + 1) * 8 - len(idx) * 8                # [indptr][idx][val] close the file
+    idx_at = sparse_at + (n + 1) * 8
+    bad = bytearray(good)
+    bad[idx_at + 40:idx_at + 44] = struct.pack("<i", V + 123)         # an index outside [0, sparse_dim)
+    refused(bytes(bad), "index_out_of_range")
+    bad = bytearray(good)
+    bad[idx_at + 4:idx_at + 8] = bad[idx_at:idx_at + 4]               # a duplicate (not strictly ascending) index
+    refused(bytes(bad), "not_ascending")
+    bad = bytearray(good)
+    bad[sparse_at + 16:sparse_at + 24] = struct.pack("<q", 10 ** 12)  # a row pointer beyond the entries
+    refused(bytes(bad), "row_pointer")
+    bad = bytearray(good)
+    val_at = idx_at + len(idx) * 4
+    bad[val_at:val_at + 4] = struct.pack("<f", float("nan"))
+    refused(bytes(bad), "nan_weight")
+    bad = bytearray(good)
+    bad[48:56] = struct.pack("<q", 1 << 62)                           # absurd n_rows in the header
+    refused(bytes(bad), "header")
+    h.close()
+
+
+def test_dev_searches_sharing_a_stream_are_serialised(gpu):
+    """The reference's service admits 64 concurrent retrieve() calls; with the device-resident query cache they all
+    reach hr_search_dense_dev from worker threads on ONE stream.  Every thread must get its own query's answer."""
+    rng = np.random.default_rng(8)
+    n, d, k, T, reps = 20000, 128, 20, 16, 12
+    X = rng.standard_normal((n, d)).astype(np.float16)
+    Q = rng.standard_normal((T, d)).astype(np.float32)
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE)
+    h.add_dense(X)
+    h.finalize()
+    want_i, want_s = h.search_dense(Q, k)
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.current_stream(dev)
+    dq = [torch.from_numpy(Q[t:t + 1]).to(dev) for t in range(T)]
+    errors = []
+    start = threading.Barrier(T)
+
+    def worker(t):
+        try:
+            ids = torch.empty((1, k), dtype=torch.int64, device=dev)
+            sc = torch.empty((1, k), dtype=torch.float32, device=dev)
+            fl = torch.zeros((1,), dtype=torch.int32, device=dev)
+            start.wait()
+            for _ in range(reps):
+                h.search_dense_dev(dq[t].data_ptr(), 1, k, ids.data_ptr(), sc.data_ptr(), fl.data_ptr(), 0, stream.cuda_stream)
+                stream.synchronize()
+                if not (np.array_equal(ids.cpu().numpy()[0], want_i[t]) and np.array_equal(_bits(sc.cpu().numpy()[0]), _bits(want_s[t]))):
+                    errors.append(t)
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    h.close()
