@@ -41,6 +41,7 @@ sys.path.insert(0, ROOT)
 SPARSE_DIM = 10000
 SPARSE_NNZ = 100
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16 MFMA
 
 
 def dense_block(block: int, n: int, dim: int, seed: int = 1234) -> np.ndarray:
@@ -60,18 +61,74 @@ def sparse_block(block: int, n: int, seed: int = 5678):
     return indptr, idx.reshape(-1), val.reshape(-1)
 
 
-def pmc_traffic(rows: int, dim: int, batch: int, n_gpus: int):
-    """HBM bytes per dense-scan launch from the committed PMC passes (profiles/r*_pmc_traffic.json:
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, FETCH doubled as the
-    gfx950 guide prescribes).  Only returned when the profiled workload is the one being run."""
+ZIPF_S = 1.1
+
+
+def zipf_term_probs(V: int = SPARSE_DIM, mean_nnz: float = SPARSE_NNZ, s: float = ZIPF_S) -> np.ndarray:
+    """P(term t occurs in a doc) = min(1, c / (t + 1)^s) with c such that a doc holds `mean_nnz` terms on average:
+    the Zipfian shape of real BM25 postings: at V = 10 000 / 100 terms per doc some twenty terms occur in
+    every doc, term 32 in half of them, the tail in fewer than 1 in 1 000."""
+    w = 1.0 / np.arange(1, V + 1, dtype=np.float64) ** s
+    lo, hi = 0.0, float(V)
+    for _ in range(60):  # bisection on c
+        c = 0.5 * (lo + hi)
+        if np.minimum(1.0, c * w).sum() > mean_nnz:
+            hi = c
+        else:
+            lo = c
+    return np.minimum(1.0, 0.5 * (lo + hi) * w)
+
+
+def sparse_block_zipf(block: int, n: int, seed: int = 5678, V: int = SPARSE_DIM, mean_nnz: float = SPARSE_NNZ):
+    """n sparse docs whose terms follow zipf_term_probs (independent per term), |N(0,1)| fp32 values, CSR with
+    ascending distinct indices per row.  Heavy terms (p >= 1/8) are drawn as a Bernoulli matrix, the tail by a Poisson
+    number of inverse-CDF draws per doc (duplicates dropped)."""
+    rng = np.random.default_rng(seed + block)
+    p = zipf_term_probs(V, mean_nnz)
+    n_head = int((p >= 0.125).sum())
+    head = rng.random((n, n_head), dtype=np.float32) < p[:n_head].astype(np.float32)
+    hd, ht = np.nonzero(head)
+    tail_p = p[n_head:]
+    lam = float(tail_p.sum())
+    k = rng.poisson(lam, size=n)
+    td = np.repeat(np.arange(n, dtype=np.int64), k)
+    tt = n_head + np.searchsorted(np.cumsum(tail_p) / lam, rng.random(td.shape[0]), side="right")
+    tt = np.minimum(tt, V - 1)
+    key = np.concatenate([hd.astype(np.int64) * V + ht, td * V + tt])
+    key = np.unique(key)  # sorted by (doc, term), duplicates of the tail draws dropped
+    doc = key // V
+    idx = (key - doc * V).astype(np.int32)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(doc, minlength=n), out=indptr[1:])
+    val = np.abs(rng.standard_normal(idx.shape[0], dtype=np.float32))
+    return indptr, idx, val
+
+
+def zipf_queries(rng, B: int, n_terms: int = 20, V: int = SPARSE_DIM):
+    """B queries of n_terms distinct terms drawn with the corpus' own term distribution (so frequent terms are in
+    most queries, as stop-word-free BM25 queries still have them), |N(0,1)| weights."""
+    p = zipf_term_probs(V)
+    p = p / p.sum()
+    out = []
+    for _ in range(B):
+        qi = np.sort(rng.choice(V, size=n_terms, replace=False, p=p)).astype(np.int32)
+        out.append((qi, np.abs(rng.standard_normal(n_terms)).astype(np.float32)))
+    return out
+
+
+def pmc_traffic(rows: int, dim: int, batch: int, n_gpus: int, kernel: str = "dense_scan", dist: str = "uniform"):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r*_pmc_traffic.json: separate
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this script, FETCH doubled as the gfx950 guide
+    prescribes).  Only returned when the profiled workload is the one being run."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
             w = d.get("workload", {})
-            if n_gpus == 1 and (w.get("rows"), w.get("dim"), w.get("batch")) == (rows, dim, batch):
-                return d["kernels"]["dense_scan"]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            if n_gpus == 1 and (w.get("rows"), w.get("dim"), w.get("batch"), w.get("sparse_dist", "uniform")) == (rows, dim, batch, dist) \
+                    and kernel in d["kernels"]:
+                return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
         except Exception:
             continue
     return None, None
@@ -87,11 +144,14 @@ def scan_kernel_name(B: int, dim: int) -> str:
     return "dense_scan_kernel<f16> (up to 64 queries per pass)"
 
 
-def make_queries(n_batches: int, B: int, dim: int, seed: int = 4321):
+def make_queries(n_batches: int, B: int, dim: int, seed: int = 4321, dist: str = "uniform"):
     rng = np.random.default_rng(seed)
     Q = rng.standard_normal((n_batches, B, dim), dtype=np.float32)
     sq = []
     for _ in range(n_batches):
+        if dist == "zipf":
+            sq.append(zipf_queries(rng, B))
+            continue
         _, idx, val = sparse_block(0, B, seed=int(rng.integers(1 << 30)))
         sq.append([(idx[i * SPARSE_NNZ:(i + 1) * SPARSE_NNZ], val[i * SPARSE_NNZ:(i + 1) * SPARSE_NNZ]) for i in range(B)])
     return Q, sq
@@ -117,6 +177,10 @@ def main():
                          "top_k fused candidates of every query and keep its best rerank_top_k (BASELINE config 4's '20->5')")
     ap.add_argument("--ce-seq-len", type=int, default=128)
     ap.add_argument("--no-sparse", action="store_true")
+    ap.add_argument("--sparse-dist", choices=("uniform", "zipf"), default="uniform",
+                    help="uniform = the reference's placeholder (100 uniform terms per doc, indexing.py:647-654; ~80-term queries); "
+                         "zipf = Zipfian postings (s = 1.1: some twenty terms in every doc, df = 50 %% at term 32) and 20-term "
+                         "queries drawn from the same distribution (SURVEY §7 'sparse skew')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel phase, not just the scans")
@@ -178,9 +242,12 @@ def main():
     blocks = [(b, min(blk, N - b * blk)) for b in range(lo // blk, -(-hi // blk))] if n_local else []
     workers = max(1, min(12, (os.cpu_count() or 8) // max(1, min(world, 8) if world > 1 else 1)))
 
+    sparse_gen = sparse_block_zipf if args.sparse_dist == "zipf" else sparse_block
+    df = np.zeros(SPARSE_DIM, dtype=np.int64)  # postings per term in this rank's shard (for the sparse roofline)
+
     def gen(bn):
         b, n = bn
-        return b, dense_block(b, n, D), (sparse_block(b, n) if use_sparse else None)
+        return b, dense_block(b, n, D), (sparse_gen(b, n) if use_sparse else None)
 
     with ThreadPoolExecutor(max_workers=workers) as pool:
         pending = []
@@ -197,11 +264,12 @@ def main():
             h.add_dense(Xb)  # fp32 -> fp16 (RNE) on the device
             if use_sparse:
                 h.add_sparse(*Sb)
+                df += np.bincount(Sb[1], minlength=SPARSE_DIM)
             if do_cpu and b * blk < cpu_rows:
                 take = min(Xb.shape[0], cpu_rows - b * blk)
                 sample_dense.append(Xb[:take].astype(np.float16))
                 if use_sparse:
-                    sample_sparse.append((Sb[1][:take * SPARSE_NNZ], Sb[2][:take * SPARSE_NNZ]))
+                    sample_sparse.append((Sb[0][:take + 1], Sb[1][:Sb[0][take]], Sb[2][:Sb[0][take]]))
             del Xb, Sb
     h.finalize()
     torch.cuda.synchronize()
@@ -209,7 +277,7 @@ def main():
 
     # ---- queries (resident in HBM before the timed region) --------------------------------------------
     n_batches = 8
-    Q, SQ = make_queries(n_batches, B, D)
+    Q, SQ = make_queries(n_batches, B, D, dist=args.sparse_dist)
     cfg = EngineConfig(top_k=args.top_k, use_sparse=use_sparse)
     n_fly = max(1, args.in_flight) if use_sparse else 1
     eng = PipelinedSearchEngine(h, cfg, device=str(dev), depth=n_fly) if n_fly > 1 else \
@@ -234,9 +302,9 @@ def main():
         ok = bool(np.array_equal(gids, oids) and np.array_equal(gsc.view(np.uint32), osc.view(np.uint32)))
         fused_ok = True
         if use_sparse:
-            s_idx = np.concatenate([p[0] for p in sample_sparse])
-            s_val = np.concatenate([p[1] for p in sample_sparse])
-            s_ptr = np.arange(n_s + 1, dtype=np.int64) * SPARSE_NNZ
+            s_idx = np.concatenate([p[1] for p in sample_sparse])
+            s_val = np.concatenate([p[2] for p in sample_sparse])
+            s_ptr = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(p[0]) for p in sample_sparse]))]).astype(np.int64)
             sids, ssc = h.search_sparse(SQ[0][:n_gate], kp, 0.2, mask)
             osids, ossc = oracle.sparse_search(s_ptr, s_idx, s_val, SQ[0][:n_gate], kp, 0.2)
             ok = ok and bool(np.array_equal(sids, osids) and np.array_equal(ssc.view(np.uint32), ossc.view(np.uint32)))
@@ -327,9 +395,35 @@ def main():
         dist.all_gather(allc, chk)
         ranks_agree = all(int(c.item()) == int(allc[0].item()) for c in allc)
 
+    # Roofline of the dominant kernel, per STEP: SURVEY §8(d) counts ONE pass over the shard for the B queries of a
+    # step, so a batch that takes several scan launches (256 queries at D = 1024: two 128-query passes) is charged
+    # all of them.  passes_per_step = 1 on the default workload, where per-step and per-launch figures coincide.
     scan_ms, scan_launches = phases["dense_scan"]
     scan_bytes = h.dense_scan_bytes
-    achieved = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    passes = scan_launches / args.steps if args.steps else 1.0
+    step_scan_ms = scan_ms * passes
+    achieved = scan_bytes / (step_scan_ms * 1e-3) / 1e9 if step_scan_ms > 0 else 0.0
+    per_launch = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    dpad = -(-D // 128) * 128
+    mfma_tflops = 2.0 * n_local * dpad * B / (step_scan_ms * 1e-3) / 1e12 if step_scan_ms > 0 else 0.0
+
+    # Sparse scan roofline: algorithmic bytes of one launch = every posting of every kept query term
+    # (4 B: fp16 weight | u16 slot) + 2 * 4 B of run bounds per (term, range), averaged over the query batches timed.
+    sparse_roof = None
+    if use_sparse:
+        sp_ms, sp_launches = phases["sparse_scan"]
+        n_ranges = -(-n_local // 16384)
+        per_batch = []
+        for sq in SQ:
+            _, kept_idx, _, _ = pack_sparse_queries(sq, 0.2)
+            per_batch.append(4 * int(df[kept_idx].sum()) + 8 * n_ranges * int(kept_idx.shape[0]))
+        sp_bytes = float(np.mean(per_batch))
+        sp_achieved = sp_bytes / (sp_ms * 1e-3) / 1e9 if sp_ms > 0 else 0.0
+        sp_traffic, sp_src = pmc_traffic(N, D, B, world, kernel="sparse_scan", dist=args.sparse_dist)
+        sparse_roof = {"bound": "hbm", "kernel": "sparse_scan_kernel", "achieved": sp_achieved, "peak": HBM_PEAK_GBPS,
+                       "unit": "GB/s", "frac": sp_achieved / HBM_PEAK_GBPS, "traffic": sp_traffic, "traffic_source": sp_src,
+                       "algorithmic_bytes_per_launch": sp_bytes, "avg_launch_ms": sp_ms, "launches": sp_launches,
+                       "postings_per_query": float(np.mean(per_batch)) / 4 / B, "distribution": args.sparse_dist}
 
     # ---- p50 latency of single-query retrieve() through the Python API ---------------------------------------------
     # N = 1: the manager holds the one shard.  N > 1: the collection spans the ranks (torchrun form of the sharded
@@ -375,7 +469,7 @@ def main():
             "metric": "queries_per_sec_hybrid_retrieve", "value": total_q / elapsed, "unit": "queries/s",
             "n_gpus": world, **({"rehearsal_single_gpu_gloo": True} if rehearsal else {}), "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{N}x{D} fp16 COSINE corpus" + (f" + sparse {SPARSE_NNZ}nnz/{SPARSE_DIM}d" if use_sparse else "")
+            "config": {"workload": f"{N}x{D} fp16 COSINE corpus" + (f" + sparse {SPARSE_NNZ}nnz/{SPARSE_DIM}d" + (" zipf(1.1)" if args.sparse_dist == "zipf" else "") if use_sparse else "")
                        + (f", hybrid dense+sparse k'={kp} -> RRF(k=60, 0.7/0.3)" if use_sparse else f", dense only k'={kp} -> RRF(k=60) of the one list")
                        + f" top_k={args.top_k} -> learned-ranker rerank {args.top_k}->{cfg.rerank_top_k}, batch {B} queries/step "
                        + (ce_note if ce_note else ("(BASELINE config 4 without the cross-encoder forward)" if (N, D) == (10_000_000, 768) and use_sparse
@@ -386,7 +480,12 @@ def main():
             "roofline": {"bound": "hbm", "kernel": scan_kernel_name(B, D), "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches},
+                         "algorithmic_bytes_per_launch": scan_bytes, "avg_launch_ms": scan_ms, "launches": scan_launches,
+                         "passes_per_step": passes, "per_launch_frac": per_launch / HBM_PEAK_GBPS,
+                         # the batched distance is a dense contraction once B >= 16: its share of the fp16 MFMA peak
+                         "mfma": {"achieved": mfma_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS}},
+            "roofline_sparse": sparse_roof,
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
             "all_lists_proven_exact": flags_exact, **({"ranks_agree": ranks_agree} if ranks_agree is not None else {}),

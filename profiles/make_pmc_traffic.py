@@ -2,7 +2,7 @@
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d <dir_f> -o f -- python3 bench.py <args>
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d <dir_w> -o w -- python3 bench.py <args>
-    python profiles/make_pmc_traffic.py <f_counter_collection.csv> <w_counter_collection.csv> rows dim batch > profiles/rN_pmc_traffic.json
+    python profiles/make_pmc_traffic.py <f_counter_collection.csv> <w_counter_collection.csv> rows dim batch [uniform|zipf] > profiles/rN_pmc_traffic.json
 
 Counters are KiB per dispatch.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B,
 /opt/skills/guides/MI355X_MICROARCH.md, HBM section); WRITE_SIZE is used as is.  Only dispatches of the full-size
@@ -32,6 +32,7 @@ def per_kernel(path, counter):
 
 def main():
     f_csv, w_csv, rows, dim, batch = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    sparse_dist = sys.argv[6] if len(sys.argv) > 6 else "uniform"
     fetch, write = per_kernel(f_csv, "FETCH_SIZE"), per_kernel(w_csv, "WRITE_SIZE")
     kernels = {}
     for key in KERNELS:
@@ -49,7 +50,7 @@ def main():
     if "dense_scan" in kernels:
         kernels["dense_scan"]["algorithmic_bytes_per_launch"] = rows * dpad * 2 + 4 * rows
     json.dump({"_how": __doc__.strip().splitlines()[0] + " — see profiles/make_pmc_traffic.py",
-               "workload": {"rows": rows, "dim": dim, "batch": batch, "top_k": 20}, "kernels": kernels},
+               "workload": {"rows": rows, "dim": dim, "batch": batch, "top_k": 20, "sparse_dist": sparse_dist}, "kernels": kernels},
               sys.stdout, indent=1)
 
 

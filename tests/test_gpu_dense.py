@@ -200,3 +200,28 @@ def test_256_query_pass_queries_in_registers(gpu, metric, n, B):
         assert np.array_equal(ids[pick], oids)
         assert np.array_equal(_bits(sc[pick]), _bits(osc))
     h.close()
+
+
+@pytest.mark.parametrize("n,B", [(3333, 1), (3333, 64), (70001, 128), (70001, 256), (20000, 300)])
+def test_config5_shape_d1024_fp16(gpu, n, B):
+    """BASELINE config 5's row shape (D = 1024 fp16, i.e. 32 tiles per row block; B up to 256 and a ragged 300):
+    every batch size takes its scan kernel for KT = 32 and must give the oracle's lists — with a row mask, a
+    duplicated row, a ragged tail group and ragged appends."""
+    rng = np.random.default_rng(n + B)
+    d = 1024
+    X = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    X[n // 2] = X[7]
+    Q = rng.standard_normal((B, d)).astype(np.float32)
+    Q[min(1, B - 1)] = X[7].astype(np.float32)
+    h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE)
+    h.add_dense(X[: n // 3])
+    h.add_dense(X[n // 3:])
+    h.finalize()
+    pick = sorted(set([0, 1, 15, 16, 63, 64, 127, 128, 129, 255, 256, B - 1, B // 2]) & set(range(B)))
+    k = 40
+    for m in (None, np.packbits(rng.random(n) < 0.6, bitorder="little")):
+        ids, sc = h.search_dense(Q, k, m)
+        oids, osc = oracle.dense_search(X, Q[pick], k, oracle.COSINE, m)
+        assert np.array_equal(ids[pick], oids)
+        assert np.array_equal(_bits(sc[pick]), _bits(osc))
+    h.close()
