@@ -611,6 +611,238 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// 256-query scan as a tiled contraction (any KT, fp16 shards): BASELINE config 5's shape (D = 1024, B = 256).
+//
+// 256 queries x 1024 dims of fp16 are 512 KiB — as much as a CU's whole register file — so for this shape the queries
+// can be stationary neither in registers (dense_scan_qreg_kernel: D = 768 only) nor in LDS; two 128-query passes read
+// the corpus twice (0.37 of the HBM peak per step however fast each pass is).  Here BOTH operands stream through LDS
+// and the block keeps a 256-row x 256-query accumulator tile in registers, the structure of a dense GEMM:
+//   * block = 8 waves as 2 (row halves) x 4 (query quarters): a wave owns 128 rows x 64 queries = 8 x 4 MFMA tiles of
+//     16 x 16, 128 accumulator registers, for the whole k loop of a row tile;
+//   * per k-step (one 1 KiB tile = 32 dims) the block needs 16 corpus tiles (HBM) and 16 query fragments (L2: the
+//     fragment set is re-read once per 256 rows, 1 byte of L2 traffic per byte of HBM traffic);
+//   * waves 0-3 are the corpus loaders, waves 4-7 the query loaders (global_load_lds_dwordx4, 4 tiles per wave and
+//     step): the two streams need different run-ahead (HBM: 5 steps, L2: 2) and a wave's vmcnt retires in issue
+//     order, so one wave must not carry both; every wave computes;
+//   * one LDS-only barrier per k-step: wait for the own loads of the step (counted vmcnt, the newer steps' loads stay
+//     in flight), barrier, refill the slots everybody has just left, 12 fragment reads (inline asm, see
+//     dense_scan_qreg_kernel), 32 MFMAs;
+//   * epilogue per row tile as in the other scans (scale, mask, maximum per candidate group), row scales by LDS-DMA.
+// MFMA time per step is 2 waves x 32 x 16 cycles per SIMD for 16 KiB of corpus: the matrix pipe, not HBM, is the
+// nearer bound (SURVEY §7 "batch = 256 is a GEMM"); bench.py reports both fractions.
+constexpr int kGemmRowBlocks = 16;               // row blocks per block tile (256 rows)
+constexpr int kGemmDA = 6, kGemmDB = 3;          // ring depth (k-steps) of the corpus / query stream
+
+template <int GQ, int NRB>                       // GQ query groups of 16 per pass: 16 (256 queries) or 8 (128)
+__global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
+    const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
+    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int KT, int64_t n_rows, int64_t n_super) {
+    static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
+    static_assert(GQ == 16 || GQ == 8, "four query quarters of 4 or 2 groups");
+    constexpr int DA = kGemmDA, DB = kGemmDB, RB = kGemmRowBlocks;
+    constexpr int LA = RB / 4, LB = GQ / 4;      // tiles a loader wave moves per step
+    constexpr int WA = RB / 2, WB = GQ / 4;      // fragments a wave reads per step: its row blocks, its query groups
+    __shared__ chunk_t ringA[DA * RB * kTileChunks];
+    __shared__ chunk_t ringB[DB * GQ * kTileChunks];
+    __shared__ f32x4_t sc_lds[2][RB * kRowsPerBlock / 4];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wr = wid >> 2, wq = wid & 3;       // row half, query quarter this wave computes
+    const bool loads_a = wid < 4;
+    const int lw = wid & 3;                      // loader index within its stream
+    const int quad = lane >> 4;
+    const float NEG_INF = -__builtin_inff();
+    const unsigned a_lds = (unsigned)(uintptr_t)(hr_lptr_t)ringA, b_lds = (unsigned)(uintptr_t)(hr_lptr_t)ringB;
+    const unsigned sc_addr = (unsigned)(uintptr_t)(hr_lptr_t)&sc_lds[0][0];
+    const int64_t n_rb = n_super * kRowBlocksPerSuper;                  // row blocks that exist in the shard
+    const int64_t n_tiles = (n_rb + RB - 1) / RB;
+    const int64_t first = blockIdx.x, stride = gridDim.x;
+    if (first >= n_tiles) return;  // whole block
+    const int64_t my_tiles = (n_tiles - first + stride - 1) / stride;
+    const int64_t total_steps = my_tiles * KT;
+    const int64_t gmax_stride = n_super * (kRowBlocksPerSuper / NRB);
+
+    // ---- loaders.  Step S = (tile index i = S / KT, k-tile kt = S % KT); past the end: harmless re-reads keep the counts fixed.
+    int64_t la_tile = first;
+    int la_kt = 0, lb_kt = 0, la_slot = 0, lb_slot = 0;
+    int64_t la_S = 0;
+    int la_sc = 0;  // scale buffer of the tile the loader is in
+    auto issue_a = [&]() {  // corpus tiles of step la_S into ring slot la_S % DA
+        const int64_t t = la_S < total_steps ? la_tile : first;
+#pragma unroll
+        for (int l = 0; l < LA; ++l) {
+            int64_t rb = t * RB + lw + 4 * l;
+            if (rb >= n_rb) rb = 0;  // row blocks past the shard: any valid tile, the epilogue masks the rows
+            const chunk_t* src = tiles + (rb * KT + la_kt) * kTileChunks + lane;
+            __builtin_amdgcn_global_load_lds((hr_gptr_t)src, (hr_lptr_t)(ringA + ((la_slot * RB) + lw + 4 * l) * kTileChunks), 16, 0,
+                                             2 /* nt: each byte is read once */);
+        }
+        if (la_kt == 0) {  // the tile's 256 row scales (64 per loader wave), needed KT steps from now
+            int64_t row = t * (RB * kRowsPerBlock) + lw * 64 + lane;
+            if (row >= n_rb * kRowsPerBlock) row = 0;
+            __builtin_amdgcn_global_load_lds((hr_gptr_t)(scale + row),
+                                             (hr_lptr_t)(reinterpret_cast<float*>(&sc_lds[la_sc][0]) + lw * 64), 4, 0, 0);
+        }
+        ++la_S;
+        la_slot = la_slot + 1 == DA ? 0 : la_slot + 1;
+        if (++la_kt == KT) { la_kt = 0; la_tile += stride; la_sc ^= 1; }
+    };
+    auto issue_b = [&]() {  // query fragments of the next step of the query stream into its ring slot
+#pragma unroll
+        for (int l = 0; l < LB; ++l) {
+            const chunk_t* src = qfrag + ((int64_t)(lw + 4 * l) * KT + lb_kt) * kTileChunks + lane;
+            __builtin_amdgcn_global_load_lds((hr_gptr_t)src, (hr_lptr_t)(ringB + ((lb_slot * GQ) + lw + 4 * l) * kTileChunks), 16, 0, 0);
+        }
+        lb_slot = lb_slot + 1 == DB ? 0 : lb_slot + 1;
+        if (++lb_kt == KT) lb_kt = 0;
+    };
+    // fragments of one step: this wave's WA corpus tiles and WB query fragments (inline asm, see dense_scan_qreg_kernel)
+    auto read_frags = [&](int sa, int sb, chunk_t (&a)[WA], chunk_t (&b)[WB]) {
+        const unsigned aa = a_lds + (unsigned)(((sa * RB) + wr * WA) * kTileChunks + lane) * 16u;
+        const unsigned ba = b_lds + (unsigned)(((sb * GQ) + wq * WB) * kTileChunks + lane) * 16u;
+#pragma unroll
+        for (int g = 0; g < WB; ++g)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b[g]) : "v"(ba), "n"(g * 1024) : "memory");
+#pragma unroll
+        for (int r = 0; r < WA; ++r)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[r]) : "v"(aa), "n"(r * 1024) : "memory");
+    };
+    auto settle = [&](chunk_t (&a)[WA], chunk_t (&b)[WB]) {  // the reads above have returned
+        __builtin_amdgcn_sched_barrier(0);  // the MFMAs issued before this point stay there: they are what the wait hides behind
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])::"memory");
+#pragma unroll
+        for (int g = 0; g < WB; ++g) asm volatile("" : "+v"(b[g]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto wait_landed = [&]() {  // own loads of the next step to be read have landed: only newer steps' loads were issued after them
+        if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 2) * LA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * LB) : "memory");
+    };
+
+    if (loads_a) {
+#pragma unroll 1
+        for (int s = 0; s < DA - 1; ++s) issue_a();
+    } else {
+#pragma unroll 1
+        for (int s = 0; s < DB - 1; ++s) issue_b();
+    }
+    f32x4_t acc[WA][WB];
+#pragma unroll
+    for (int r = 0; r < WA; ++r)
+#pragma unroll
+        for (int g = 0; g < WB; ++g) acc[r][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    chunk_t a0[WA], b0[WB], a1[WA], b1[WB];  // fragments of the current / the next step
+    wait_landed();
+    lds_barrier();
+    if (loads_a) issue_a(); else issue_b();
+    read_frags(0, 0, a0, b0);
+    settle(a0, b0);
+
+    int kt = 0, sa = 0, sb = 0;  // k-tile and ring slots of the step being multiplied
+    int64_t tile = first;
+    int sci = 0;
+    // One step: the first half of its MFMAs, then (data of the next step landed, barrier, refill, fragment reads of the next
+    // step into the other register set) under the second half.
+    auto step = [&](chunk_t (&ca)[WA], chunk_t (&cb)[WB], chunk_t (&na)[WA], chunk_t (&nb)[WB], bool more) {
+#pragma unroll
+        for (int r = 0; r < WA / 2; ++r)
+#pragma unroll
+            for (int g = 0; g < WB; ++g) Mfma<_Float16>::run(ca[r], cb[g], acc[r][g]);
+        const int nsa = sa + 1 == DA ? 0 : sa + 1, nsb = sb + 1 == DB ? 0 : sb + 1;
+        if (more) {
+            wait_landed();
+            lds_barrier();  // everybody's loads of the next step have landed; everybody has read this step's fragments
+            if (loads_a) issue_a(); else issue_b();
+            read_frags(nsa, nsb, na, nb);
+        }
+#pragma unroll
+        for (int r = WA / 2; r < WA; ++r)
+#pragma unroll
+            for (int g = 0; g < WB; ++g) Mfma<_Float16>::run(ca[r], cb[g], acc[r][g]);
+        if (more) settle(na, nb);
+        sa = nsa;
+        sb = nsb;
+    };
+    auto epilogue = [&]() {
+        // lane holds rows quad*4..+3 of each of its WA row blocks for query (lane & 15) of each of its WB groups
+        const int64_t rb0 = tile * RB + wr * WA;   // first row block of this wave
+        const bool tail = (rb0 + WA) * kRowsPerBlock > n_rows || rowmask != nullptr;
+        float m[2][WB];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int g = 0; g < WB; ++g) m[h2][g] = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < WA; ++r) {
+            const int64_t row0 = (rb0 + r) * kRowsPerBlock + quad * 4;
+            f32x4_t sc;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(sc)
+                         : "v"(sc_addr + (unsigned)((sci * (RB * kRowsPerBlock / 4) + (wr * WA + r) * (kRowsPerBlock / 4) + quad) * 16))
+                         : "memory");
+            float ok[4] = {1.f, 1.f, 1.f, 1.f};
+            if (tail) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int64_t row = row0 + x;
+                    bool v = row < n_rows;
+                    if (v && rowmask) v = (rowmask[row >> 3] >> (row & 7)) & 1;
+                    ok[x] = v ? 1.f : 0.f;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < WB; ++g) {
+                float mr = NEG_INF;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    float v = acc[r][g][x] * sc[x];
+                    v = (ok[x] != 0.f) ? v : NEG_INF;
+                    mr = fmaxf(mr, v);
+                }
+                acc[r][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (NRB == 1) {
+                    mr = fmaxf(mr, __shfl_xor(mr, 16));
+                    mr = fmaxf(mr, __shfl_xor(mr, 32));
+                    const int q = 16 * (wq * WB + g) + (lane & 15);
+                    if (lane < 16 && q < nq && rb0 + r < n_rb) gmax[(int64_t)q * gmax_stride + rb0 + r] = mr;
+                } else {
+                    m[r / kRowBlocksPerSuper][g] = fmaxf(m[r / kRowBlocksPerSuper][g], mr);
+                }
+            }
+        }
+        if (NRB != 1) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int64_t sg = rb0 / kRowBlocksPerSuper + h2;
+#pragma unroll
+                for (int g = 0; g < WB; ++g) {
+                    float v = m[h2][g];
+                    v = fmaxf(v, __shfl_xor(v, 16));
+                    v = fmaxf(v, __shfl_xor(v, 32));
+                    const int q = 16 * (wq * WB + g) + (lane & 15);
+                    if (lane < 16 && q < nq && sg < n_super) gmax[(int64_t)q * gmax_stride + sg] = v;
+                }
+            }
+        }
+        tile += stride;
+        sci ^= 1;
+    };
+#pragma unroll 1
+    for (int64_t S = 0; S < total_steps; S += 2) {  // KT is even: a row tile ends after an odd step
+        step(a0, b0, a1, b1, true);                  // an even step always has a successor
+        step(a1, b1, a0, b0, S + 2 < total_steps);
+        kt += 2;
+        if (kt == KT) {
+            kt = 0;
+            epilogue();
+        }
+    }
+    // LDS DMA still in flight must land before the block's LDS is handed to another block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------
 // Canonical refine: 64 candidate rows per wave (group_rows = 16 or 64 rows per candidate group); lane = row.
 // score = (float) S with S the k-ordered fp64 sum of exact products.  The same
 // arithmetic is restated in oracle/oracle.c:dense_score().

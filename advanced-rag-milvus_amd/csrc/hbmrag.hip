@@ -383,6 +383,25 @@ hipError_t launch_scan_qreg_g(const hr_index* h, hipStream_t s, const chunk_t* q
     return group_rows_for(h, h->n_rows) == 16 ? launch_scan_qreg<24, 1, 2, 8>(h, s, qfrag, mask, gmax, nq, n_super)
                                               : launch_scan_qreg<24, 4, 2, 8>(h, s, qfrag, mask, gmax, nq, n_super);
 }
+// 256-query pass as a tiled contraction (dense_scan_gemm_kernel): fp16 shards of any row length from 8 tiles up;
+// serves the shapes the register-resident form cannot (D = 1024: BASELINE config 5).  HBMRAG_GEMM=1 prefers it
+// to the qreg form at D = 768 too (A/B).
+bool gemm_supported(const hr_index* h) {
+    static const bool off = std::getenv("HBMRAG_NO_GEMM") != nullptr;
+    return !off && h->dtype == HR_F16 && h->KT >= 8;
+}
+hipError_t launch_scan_gemm_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                              int nq, int64_t n_super) {
+    const int64_t n_tiles = (n_super * kRowBlocksPerSuper + kGemmRowBlocks - 1) / kGemmRowBlocks;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_tiles, h->cu_count));
+    if (group_rows_for(h, h->n_rows) == 16)
+        hipLaunchKernelGGL((dense_scan_gemm_kernel<16, 1>), dim3(blocks), dim3(512), 0, s, h->tiles.as<chunk_t>(), qfrag,
+                           h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
+    else
+        hipLaunchKernelGGL((dense_scan_gemm_kernel<16, 4>), dim3(blocks), dim3(512), 0, s, h->tiles.as<chunk_t>(), qfrag,
+                           h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
+    return hipGetLastError();
+}
 int max_groups_for_dim(const hr_index* h) {
     // query tile must fit LDS: G * KT KiB <= 144 KiB
     int g = 156 / std::max(h->KT, 1);
@@ -448,7 +467,9 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     // batches beyond what fits LDS whole go through the k-chunked large-batch pass, 128 or 256 queries at a time
     static const bool no_bigq = std::getenv("HBMRAG_NO_BIGQ") != nullptr;
     const bool big = B > 16 * Gsmall && h->KT % 4 == 0 && !no_bigq;
-    const bool big256 = big && B > 128 && qreg_supported(h);   // 256 queries per pass, queries in registers
+    static const bool prefer_gemm = std::getenv("HBMRAG_GEMM") != nullptr;
+    const bool use_qreg = qreg_supported(h) && !(prefer_gemm && gemm_supported(h));
+    const bool big256 = big && B > 128 && (use_qreg || gemm_supported(h));   // 256 queries per pass
     const int Gmax = big256 ? 16 : big ? 8 : Gsmall;
     const int chunk_q = 16 * Gmax;
     const size_t qfrag_bytes = (size_t)Gmax * h->KT * 1024;
@@ -481,7 +502,8 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
             float* gm = ws->gmax.as<float>() + (int64_t)c0 * n_groups;
             hipError_t e;
             if (pass256)
-                e = launch_scan_qreg_g(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+                e = use_qreg ? launch_scan_qreg_g(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
+                             : launch_scan_gemm_g(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
             else if (big)
                 e = (h->dtype == HR_F16)
                         ? launch_scan_bigq_g<_Float16>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
@@ -780,7 +802,8 @@ int build_sparse(hr_index* h) {
     HIP_TRY(h, tmp.cursor.ensure((size_t)dirty * V1 * 4));
     HIP_TRY(h, hipMemcpyAsync(tmp.cursor.p, h->rt_off.as<unsigned int>() + r_d * V1, (size_t)dirty * V1 * 4,
                               hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(sparse_fill_kernel, dim3(doc_blocks), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
+    // (the fill kernel permutes docs inside aligned blocks of 128: its grid covers whole blocks)
+    hipLaunchKernelGGL(sparse_fill_kernel, dim3((unsigned)((round_up(n - doc0, 128) + 255) / 256)), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
                        h->s_idx.as<int32_t>(), h->s_val.as<float>(), doc0, n, V1, tmp.cursor.as<unsigned int>(),
                        h->range_base.as<int64_t>(), h->post.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());

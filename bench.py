@@ -330,9 +330,18 @@ def main():
         mask = torch.ones((B * args.top_k, T), dtype=torch.bool, device=dev)
         ce_out = {}
 
+        ce_events = []
+
         def cross_encode(b):
             # synthetic token ids derived from (query slot, fused doc id, position): there is no text behind the
             # random corpus; the forward pass (the cost being measured) does not depend on what the tokens are
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(dev))
+            _cross_encode(b)
+            ev1.record(torch.cuda.current_stream(dev))
+            ce_events.append((ev0, ev1))
+
+        def _cross_encode(b):
             doc = b["fused_ids"].clamp_min(0)[:, :, None]
             toks = (1000 + (doc * 7919 + pos * 104729 + torch.arange(B, device=dev)[:, None, None] * 31) % (vocab - 1000))
             toks = toks.view(B * args.top_k, T)
@@ -360,6 +369,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    if args.rerank == "cross-encoder":
+        ce_events.clear()
     h.kernel_ms()  # drop warm-up spans
     h.set_profiling(2 if args.profile_all else 1)
     if world > 1:
@@ -486,6 +497,7 @@ def main():
                          "mfma": {"achieved": mfma_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS}},
             "roofline_sparse": sparse_roof,
+            **({"cross_encoder": ce_report(ce, ce_events, B * args.top_k, args.ce_seq_len)} if args.rerank == "cross-encoder" else {}),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
             "all_lists_proven_exact": flags_exact, **({"ranks_agree": ranks_agree} if ranks_agree is not None else {}),
@@ -498,6 +510,20 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def ce_report(ce, events, pairs: int, T: int):
+    """Forward pass of the cross-encoder leg (BASELINE config 4's rerank 20 -> 5; north_star assigns it to PyTorch-ROCm):
+    device ms per step from events around the forward, its arithmetic (per token and layer 24 H^2 for the projections and
+    the FFN + 4 T H for the attention products) and the share of the fp16 MFMA peak."""
+    cfg = ce.config
+    H, L = cfg.hidden, cfg.layers
+    flops = pairs * ce.flops_per_pair(T)
+    ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else 0.0
+    tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"model": f"random-init MiniLM-L{L}-H{H} (PyTorch-ROCm, fp16)", "pairs_per_step": pairs, "seq_len": T,
+            "forward_ms_per_step": ms, "flop_per_step": flops, "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "forwards_timed": len(events)}
 
 
 def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_total=None):
