@@ -659,42 +659,65 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     const int64_t first = blockIdx.x, stride = gridDim.x;
     if (first >= n_tiles) return;  // whole block
     const int64_t my_tiles = (n_tiles - first + stride - 1) / stride;
-    const int64_t total_steps = my_tiles * KT;
+    const int total_steps = (int)(my_tiles * KT);  // rows < 2^31 and 256 rows per tile: at most 2^23 tiles x 128 k-steps
     const int64_t gmax_stride = n_super * (kRowBlocksPerSuper / NRB);
 
-    // ---- loaders.  Step S = (tile index i = S / KT, k-tile kt = S % KT); past the end: harmless re-reads keep the counts fixed.
-    int64_t la_tile = first;
-    int la_kt = 0, lb_kt = 0, la_slot = 0, lb_slot = 0;
-    int64_t la_S = 0;
-    int la_sc = 0;  // scale buffer of the tile the loader is in
-    auto issue_a = [&]() {  // corpus tiles of step la_S into ring slot la_S % DA
-        const int64_t t = la_S < total_steps ? la_tile : first;
+    // ---- loaders.  Everything but the lane's 16 bytes is wave-uniform and advances by a constant per step (1 KiB along
+    // k), so a step costs each loader wave four scalar adds and four loads; the tile's first addresses are recomputed
+    // once per row tile.  Past the block's last tile the loader wraps to its first one: harmless re-reads that keep the
+    // number of loads in flight fixed.
+    const char* const tiles_b = reinterpret_cast<const char*>(tiles);
+    const char* const qfrag_b = reinterpret_cast<const char*>(qfrag);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    unsigned long long a_off[LA], b_off[LB];
+    int la_kt = 0, lb_kt = 0, la_slot = 0, lb_slot = 0, la_sc = 0;
+    int64_t la_tile = first, la_tiles_left = my_tiles;
+    auto a_tile_setup = [&]() {
 #pragma unroll
         for (int l = 0; l < LA; ++l) {
-            int64_t rb = t * RB + lw + 4 * l;
+            int64_t rb = la_tile * RB + lw + 4 * l;
             if (rb >= n_rb) rb = 0;  // row blocks past the shard: any valid tile, the epilogue masks the rows
-            const chunk_t* src = tiles + (rb * KT + la_kt) * kTileChunks + lane;
-            __builtin_amdgcn_global_load_lds((hr_gptr_t)src, (hr_lptr_t)(ringA + ((la_slot * RB) + lw + 4 * l) * kTileChunks), 16, 0,
+            a_off[l] = (unsigned long long)rb * (unsigned long long)KT * 1024ull;
+        }
+    };
+    a_tile_setup();
+#pragma unroll
+    for (int l = 0; l < LB; ++l) b_off[l] = (unsigned long long)(lw + 4 * l) * (unsigned long long)KT * 1024ull;
+    auto issue_a = [&]() {  // the wave's corpus tiles of the loader's current step into its ring slot
+#pragma unroll
+        for (int l = 0; l < LA; ++l) {
+            __builtin_amdgcn_global_load_lds((hr_gptr_t)(tiles_b + a_off[l] + lane16),
+                                             (hr_lptr_t)(ringA + ((la_slot * RB) + lw + 4 * l) * kTileChunks), 16, 0,
                                              2 /* nt: each byte is read once */);
+            a_off[l] += 1024ull;
         }
         if (la_kt == 0) {  // the tile's 256 row scales (64 per loader wave), needed KT steps from now
-            int64_t row = t * (RB * kRowsPerBlock) + lw * 64 + lane;
+            int64_t row = la_tile * (RB * kRowsPerBlock) + lw * 64 + lane;
             if (row >= n_rb * kRowsPerBlock) row = 0;
             __builtin_amdgcn_global_load_lds((hr_gptr_t)(scale + row),
                                              (hr_lptr_t)(reinterpret_cast<float*>(&sc_lds[la_sc][0]) + lw * 64), 4, 0, 0);
         }
-        ++la_S;
         la_slot = la_slot + 1 == DA ? 0 : la_slot + 1;
-        if (++la_kt == KT) { la_kt = 0; la_tile += stride; la_sc ^= 1; }
+        if (++la_kt == KT) {
+            la_kt = 0;
+            la_sc ^= 1;
+            la_tile = --la_tiles_left > 0 ? la_tile + stride : first;
+            a_tile_setup();
+        }
     };
-    auto issue_b = [&]() {  // query fragments of the next step of the query stream into its ring slot
+    auto issue_b = [&]() {  // the wave's query fragments of the query stream's current step into its ring slot
 #pragma unroll
         for (int l = 0; l < LB; ++l) {
-            const chunk_t* src = qfrag + ((int64_t)(lw + 4 * l) * KT + lb_kt) * kTileChunks + lane;
-            __builtin_amdgcn_global_load_lds((hr_gptr_t)src, (hr_lptr_t)(ringB + ((lb_slot * GQ) + lw + 4 * l) * kTileChunks), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((hr_gptr_t)(qfrag_b + b_off[l] + lane16),
+                                             (hr_lptr_t)(ringB + ((lb_slot * GQ) + lw + 4 * l) * kTileChunks), 16, 0, 0);
+            b_off[l] += 1024ull;
         }
         lb_slot = lb_slot + 1 == DB ? 0 : lb_slot + 1;
-        if (++lb_kt == KT) lb_kt = 0;
+        if (++lb_kt == KT) {
+            lb_kt = 0;
+#pragma unroll
+            for (int l = 0; l < LB; ++l) b_off[l] -= (unsigned long long)KT * 1024ull;
+        }
     };
     // fragments of one step: this wave's WA corpus tiles and WB query fragments (inline asm, see dense_scan_qreg_kernel)
     auto read_frags = [&](int sa, int sb, chunk_t (&a)[WA], chunk_t (&b)[WB]) {
@@ -829,7 +852,7 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
         sci ^= 1;
     };
 #pragma unroll 1
-    for (int64_t S = 0; S < total_steps; S += 2) {  // KT is even: a row tile ends after an odd step
+    for (int S = 0; S < total_steps; S += 2) {  // KT is even: a row tile ends after an odd step
         step(a0, b0, a1, b1, true);                  // an even step always has a successor
         step(a1, b1, a0, b0, S + 2 < total_steps);
         kt += 2;

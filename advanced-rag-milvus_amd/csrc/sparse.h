@@ -237,6 +237,8 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
     constexpr int K = kScanK, NW = kScanWaves, DPT = kDocsPerThread;
     __shared__ int acc[kAccWords];
     __shared__ ScanTab tab[2];  // T(s) lives in tab[s & 1]
+    __shared__ unsigned run_first[kScanTermChunk], run_lo[kScanTermChunk], run_hi[kScanTermChunk];  // wave 0's scratch for long runs
+    __shared__ float run_w[kScanTermChunk];
     const int qi = blockIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * rpb;
     const int n_r = (int)min((int64_t)rpb, n_ranges - r0);
@@ -298,26 +300,66 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         unsigned first = incl - mine;
         unsigned taken = 0;  // term slots of this lane that go into the step
         unsigned used = 0;   // slots this lane's runs add to the step
+        unsigned longest = 0;
+        auto run_fits = [&](int j, unsigned start) {  // run j of this lane is in range and still fits the step's slot table
+            const int t = 4 * lane + j;
+            return t >= p_pos && t < nt && start + cnt[j] <= (unsigned)kSlots;
+        };
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int t = 4 * lane + j;
-            const bool fits = t >= p_pos && t < nt && first + cnt[j] <= (unsigned)kSlots;
-            if (fits) {
-                unsigned e = loc[j];
-#pragma unroll 1
-                for (unsigned c = 0; c < cnt[j]; ++c, e += kSlotPostings) {
-                    T.e0[first + c] = e;
-                    T.n[first + c] = min((unsigned)kSlotPostings, hic[j] - e);
-                    T.ws[first + c] = wc[j];
-                }
+            if (run_fits(j, first)) {
                 ++taken;
                 used += cnt[j];
+                longest = max(longest, cnt[j]);
             }
             first += cnt[j];
         }
+        first -= mine;
         // the prefix is monotone, so the runs that fit are exactly the first ones: their slot counts simply add up
         taken = wave_sum(taken);
         used = wave_sum(used);
+        if (!__any(longest > 8u)) {
+            // short runs (the usual case: ~3 slots each): every lane writes the slots of its own runs
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (run_fits(j, first)) {
+                    unsigned e = loc[j];
+#pragma unroll 1
+                    for (unsigned c = 0; c < cnt[j]; ++c, e += kSlotPostings) {
+                        T.e0[first + c] = e;
+                        T.n[first + c] = min((unsigned)kSlotPostings, hic[j] - e);
+                        T.ws[first + c] = wc[j];
+                    }
+                }
+                first += cnt[j];
+            }
+        } else {
+            // a long run (a frequent term: up to 256 slots) would keep ONE lane writing for thousands of cycles between
+            // the step's barriers: publish the runs, then every lane fills slots lane, lane + 64, ... by looking its run up
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t = 4 * lane + j;
+                run_first[t] = first;
+                run_lo[t] = loc[j];
+                run_hi[t] = hic[j];
+                run_w[t] = wc[j];
+                first += cnt[j];
+            }
+            const int t_end = p_pos + (int)taken;  // runs [p_pos, t_end) are in the step
+#pragma unroll 1
+            for (unsigned sl = (unsigned)lane; sl < used; sl += 64) {
+                int lo_t = p_pos, hi_t = t_end - 1;  // largest t with run_first[t] <= sl (empty runs share their successor's start)
+#pragma unroll 1
+                while (lo_t < hi_t) {
+                    const int mid = (lo_t + hi_t + 1) >> 1;
+                    if (run_first[mid] <= sl) lo_t = mid; else hi_t = mid - 1;
+                }
+                const unsigned e = run_lo[lo_t] + (sl - run_first[lo_t]) * kSlotPostings;
+                T.e0[sl] = e;
+                T.n[sl] = min((unsigned)kSlotPostings, run_hi[lo_t] - e);
+                T.ws[sl] = run_w[lo_t];
+            }
+        }
 #pragma unroll 1
         for (int i = (int)used + lane; i < kSlots; i += 64) T.n[i] = 0u;  // unused slots fetch idle postings
         const int p_end = p_pos + (int)taken;
