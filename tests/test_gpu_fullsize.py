@@ -17,6 +17,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 N, D, K, BLK = 10_000_000, 768, 40, 500_000
+V, NNZ, SBLK = 10000, 100, 250_000   # the sparse side of config 4: bench.sparse_block's placeholder docs, block by block
 
 
 def _block(b):
@@ -36,9 +37,16 @@ def _rows(ids):
     return out
 
 
+def _sparse_block(b):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import sparse_block
+    return sparse_block(b, SBLK)
+
+
 @pytest.fixture(scope="module")
 def shards(gpu):
-    whole = nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE)
+    whole = nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE, V)   # config 4: dense + sparse collections of one shard
     halves = [nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE) for _ in range(2)]
     whole.reserve(N)
     for i, h in enumerate(halves):
@@ -51,8 +59,13 @@ def shards(gpu):
         torch.cuda.synchronize()
         whole.add_dense_dev(x.data_ptr(), BLK)
         halves[b * BLK // (N // 2)].add_dense_dev(x.data_ptr(), BLK)
+    for b in range(N // SBLK):   # 10M sparse docs, appended and flushed block by block (incremental posting build)
+        whole.add_sparse(*_sparse_block(b))
+        if b % 8 == 7:
+            whole.finalize()
     for h in [whole] + halves:
         h.finalize()
+    assert whole.num_sparse_rows == N
     yield whole, halves
     for h in [whole] + halves:
         h.close()
@@ -219,3 +232,103 @@ def test_large_sparse_properties(gpu):
     assert np.array_equal(mi.cpu().numpy(), ids) and np.array_equal(ms.cpu().numpy().view(np.uint32), sc.view(np.uint32))
     for h in shards + [whole]:
         h.close()
+
+
+def test_config4_hybrid_leg_at_10m_docs(shards):
+    """The sparse / hybrid leg of BASELINE config 4 at FULL size (10M docs x 100 nnz, 611 doc ranges) through the batched
+    engine (B = 128: the bench's step): every list proven exact, spot oracle on the returned docs (rows regenerated block
+    by block) bit for bit and on sampled outsiders, the fused lists = the oracle's RRF of the device's own lists, and the
+    batch answer = the single-query host form at three batch positions."""
+    from advanced_rag.engine import EngineConfig, HybridSearchEngine, pack_sparse_queries
+    whole, _ = shards
+    B = 128
+    rng = np.random.default_rng(123)
+    Q = rng.standard_normal((B, D)).astype(np.float32)
+    SQ = []
+    for j in range(B):
+        qi = (np.arange(NNZ, dtype=np.int32) * (V // NNZ)) + rng.integers(0, V // NNZ, NNZ, dtype=np.int32)
+        SQ.append((qi, np.abs(rng.standard_normal(NNZ)).astype(np.float32)))
+    cfg = EngineConfig(top_k=20)
+    eng = HybridSearchEngine(whole, cfg)
+    out = eng.search(torch.from_numpy(Q).cuda(), eng.upload_sparse(pack_sparse_queries(SQ, 0.2, V)))
+    torch.cuda.synchronize()
+    assert out["flags"].min().item() == 1
+    sid, ssc = out["ids"][1].cpu().numpy(), out["scores"][1].cpu().numpy()
+    did = out["ids"][0].cpu().numpy()
+    assert (sid >= 0).all() and (np.diff(ssc, axis=1) <= 0).all()
+    assert (np.diff(sid, axis=1)[np.diff(ssc, axis=1) == 0] > 0).all()
+    blocks = {}
+    def doc_rows(ids):
+        ptrs, idxs, vals = [0], [], []
+        for r in ids:
+            b = int(r) // SBLK
+            if b not in blocks:
+                blocks[b] = _sparse_block(b)
+            p, i_, v_ = blocks[b]
+            lo, hi = p[int(r) % SBLK], p[int(r) % SBLK + 1]
+            idxs.append(i_[lo:hi]); vals.append(v_[lo:hi]); ptrs.append(ptrs[-1] + hi - lo)
+        return np.asarray(ptrs, np.int64), np.concatenate(idxs), np.concatenate(vals)
+    for j in (0, 63, B - 1):
+        qi, qv = oracle.drop_query(*SQ[j], 0.2)
+        want = oracle.sparse_scores(*doc_rows(sid[j]), qi, qv)
+        assert np.array_equal(want.view(np.uint32), ssc[j].view(np.uint32))
+        outsiders = rng.integers(0, 2 * SBLK, 20_000)          # sampled from two blocks: no returned doc may be beaten
+        outsiders = outsiders[~np.isin(outsiders, sid[j])]
+        assert oracle.sparse_scores(*doc_rows(outsiders), qi, qv).max() <= ssc[j, -1]
+        # fusion of the device's own lists
+        fi, fs, fm = oracle.rrf(did[j], sid[j], (), cfg.dense_weight, cfg.sparse_weight, 0.2, cfg.rrf_k)
+        nf = int(out["fused_n"][j])
+        assert np.array_equal(out["fused_ids"][j, :nf].cpu().numpy(), fi[:nf])
+        assert np.array_equal(out["fused_scores"][j, :nf].cpu().numpy().view(np.uint64), fs[:nf].view(np.uint64))
+        # batch position invariance against the host forms
+        hi_, hs_ = whole.search_sparse([SQ[j]], K, 0.2)
+        assert np.array_equal(hi_[0], sid[j]) and np.array_equal(hs_[0].view(np.uint32), ssc[j].view(np.uint32))
+        di_, _ = whole.search_dense(Q[j:j + 1], K)
+        assert np.array_equal(di_[0], did[j])
+
+
+def test_config5_fullsize_properties(gpu):
+    """BASELINE config 5 at FULL size on one GPU: 50M x 1024 fp16 (102.4 GB), B = 256 through the single-pass
+    256-query kernel.  Size-independent properties: stored rows used as queries come back first with cosine 1.0,
+    lists are ordered with the id tie rule, every list is proven exact, and the 256-query pass gives the same lists as
+    the 128-query pass and the single-query pass for the same queries."""
+    N5, D5, B5, BLK5 = 50_000_000, 1024, 256, 500_000
+    h = nat.ShardHandle(D5, nat.HR_F16, nat.HR_METRIC_COSINE)
+    h.reserve(N5)
+    keep = {}
+    for b in range(N5 // BLK5):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5000 + b)
+        x = torch.randn((BLK5, D5), device="cuda", generator=g, dtype=torch.float32).to(torch.float16)
+        if b in (0, 57, 99):
+            keep[b] = x[:3].float().cpu().numpy()
+        torch.cuda.synchronize()
+        h.add_dense_dev(x.data_ptr(), BLK5)
+        del x
+    h.finalize()
+    assert h.num_rows == N5
+    rng = np.random.default_rng(5)
+    Q = rng.standard_normal((B5, D5)).astype(np.float32)
+    planted = {0: 0, 100: 57 * BLK5 + 1, 255: 99 * BLK5 + 2}       # query slot -> row it copies
+    for slot, row in planted.items():
+        Q[slot] = keep[row // BLK5][row % BLK5]
+    dq = torch.from_numpy(Q).cuda()
+    ids = torch.empty((B5, K), dtype=torch.int64, device="cuda")
+    sc = torch.empty((B5, K), dtype=torch.float32, device="cuda")
+    fl = torch.zeros((B5,), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    h.search_dense_dev(dq.data_ptr(), B5, K, ids.data_ptr(), sc.data_ptr(), fl.data_ptr(), 0, st)
+    torch.cuda.synchronize()
+    ids, sc = ids.cpu().numpy(), sc.cpu().numpy()
+    assert int(fl.min()) == 1
+    for slot, row in planted.items():
+        assert ids[slot, 0] == row and abs(sc[slot, 0] - 1.0) < 1e-6
+    assert (ids >= 0).all() and (np.diff(sc, axis=1) <= 0).all()
+    assert (np.diff(ids, axis=1)[np.diff(sc, axis=1) == 0] > 0).all()
+    # the same queries through the 128-query pass (B = 128) and the single-query pass (B = 1)
+    i128, s128 = h.search_dense(Q[64:192], K)
+    assert np.array_equal(i128, ids[64:192]) and np.array_equal(s128.view(np.uint32), sc[64:192].view(np.uint32))
+    for slot in (0, 100, 255, 31):
+        i1, s1 = h.search_dense(Q[slot:slot + 1], K)
+        assert np.array_equal(i1[0], ids[slot]) and np.array_equal(s1[0].view(np.uint32), sc[slot].view(np.uint32))
+    h.close()
