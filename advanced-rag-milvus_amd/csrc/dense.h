@@ -621,15 +621,35 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
 //     16 x 16, 128 accumulator registers, for the whole k loop of a row tile;
 //   * per k-step (one 1 KiB tile = 32 dims) the block needs 16 corpus tiles (HBM) and 16 query fragments (L2: the
 //     fragment set is re-read once per 256 rows, 1 byte of L2 traffic per byte of HBM traffic);
-//   * waves 0-3 are the corpus loaders, waves 4-7 the query loaders (global_load_lds_dwordx4, 4 tiles per wave and
-//     step): the two streams need different run-ahead (HBM: 5 steps, L2: 2) and a wave's vmcnt retires in issue
-//     order, so one wave must not carry both; every wave computes;
-//   * one LDS-only barrier per k-step: wait for the own loads of the step (counted vmcnt, the newer steps' loads stay
-//     in flight), barrier, refill the slots everybody has just left, 12 fragment reads (inline asm, see
-//     dense_scan_qreg_kernel), 32 MFMAs;
+//   * waves 0-3 (row half 0) are the corpus loaders, waves 4-7 (row half 1) the query loaders (global_load_lds_dwordx4,
+//     4 pieces of 1 KiB per wave and step): the two streams need different run-ahead (HBM: 5 steps, L2: 2) and a wave's
+//     vmcnt retires in issue order, so one wave must not carry both; every wave computes;
+//   * the two waves of a SIMD (wave w and w + 4) run half a step apart ("ping-pong"): while one issues its 32 MFMAs of
+//     a step (with its four refill pieces between them), the other does everything else — 12 fragment reads (inline
+//     asm, see dense_scan_qreg_kernel), their wait, the landed-check of its own loads.  Two LDS-only barriers per step
+//     keep the halves in anti-phase.  With one barrier per step all eight waves wanted the matrix pipe at the same time
+//     and left it idle at the same time (stamp build: 40 % busy, the older wave of a SIMD waiting 600 cycles per step at
+//     the barrier for the younger one);
+//   * the fragment registers are single-buffered (the reads of a step do not overlap the wave's own MFMAs, they overlap
+//     the other wave's);
 //   * epilogue per row tile as in the other scans (scale, mask, maximum per candidate group), row scales by LDS-DMA.
 // MFMA time per step is 2 waves x 32 x 16 cycles per SIMD for 16 KiB of corpus: the matrix pipe, not HBM, is the
 // nearer bound (SURVEY §7 "batch = 256 is a GEMM"); bench.py reports both fractions.
+#ifdef HR_STAMP  // diagnostic build only (make stamp): where a k-step of dense_scan_gemm_kernel spends its cycles
+__device__ unsigned long long hr_gemm_stamps[2][8];
+#define GEMM_STAMP(i)                                                                                   \
+    do {                                                                                                \
+        unsigned long long t_;                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        seg[i] += t_ - t_last;                                                                          \
+        t_last = t_;                                                                                    \
+    } while (0)
+#else
+#define GEMM_STAMP(i)
+#endif
+template <bool B> struct BoolConst { static constexpr bool value = B; };
 constexpr int kGemmRowBlocks = 16;               // row blocks per block tile (256 rows)
 constexpr int kGemmDA = 6, kGemmDB = 3;          // ring depth (k-steps) of the corpus / query stream
 
@@ -640,7 +660,6 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
     static_assert(GQ == 16 || GQ == 8, "four query quarters of 4 or 2 groups");
     constexpr int DA = kGemmDA, DB = kGemmDB, RB = kGemmRowBlocks;
-    constexpr int LA = RB / 4, LB = GQ / 4;      // tiles a loader wave moves per step
     constexpr int WA = RB / 2, WB = GQ / 4;      // fragments a wave reads per step: its row blocks, its query groups
     __shared__ chunk_t ringA[DA * RB * kTileChunks];
     __shared__ chunk_t ringB[DB * GQ * kTileChunks];
@@ -662,62 +681,57 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     const int total_steps = (int)(my_tiles * KT);  // rows < 2^31 and 256 rows per tile: at most 2^23 tiles x 128 k-steps
     const int64_t gmax_stride = n_super * (kRowBlocksPerSuper / NRB);
 
-    // ---- loaders.  Everything but the lane's 16 bytes is wave-uniform and advances by a constant per step (1 KiB along
-    // k), so a step costs each loader wave four scalar adds and four loads; the tile's first addresses are recomputed
-    // once per row tile.  Past the block's last tile the loader wraps to its first one: harmless re-reads that keep the
-    // number of loads in flight fixed.
-    const char* const tiles_b = reinterpret_cast<const char*>(tiles);
-    const char* const qfrag_b = reinterpret_cast<const char*>(qfrag);
+    // ---- loaders.  One piece of code for both roles (a role is data: source, ring, depth), so that the pieces can sit
+    // between the MFMAs of a step without control flow.  Everything but the lane's 16 bytes is wave-uniform: `src` is the
+    // wave's piece 0 of the loader's current step and advances by 1 KiB per step; pieces 1-3 lie 4 row blocks / query
+    // groups further each (rel[]).  Row blocks past the shard (last tile only; row blocks come in fours) are replaced by
+    // piece 0 — harmless re-reads, the epilogue masks the rows.  Past the block's last tile the corpus loader wraps to
+    // its first one, which keeps the number of loads in flight fixed.
+    static_assert(RB == 16 && GQ == 16, "four pieces per step and loader wave, one ring geometry for both streams");
     const unsigned lane16 = (unsigned)lane * 16u;
-    unsigned long long a_off[LA], b_off[LB];
-    int la_kt = 0, lb_kt = 0, la_slot = 0, lb_slot = 0, la_sc = 0;
-    int64_t la_tile = first, la_tiles_left = my_tiles;
-    auto a_tile_setup = [&]() {
+    const unsigned pstride = (unsigned)KT * 4096u;   // 4 row blocks / query groups further, same k-step
+    const int depth = loads_a ? DA : DB;
+    chunk_t* const ring_w = (loads_a ? ringA : ringB) + lw * kTileChunks;
+    const char* src;
+    unsigned rel[4] = {0u, pstride, 2u * pstride, 3u * pstride};
+    int l_kt = 0, l_slot = 0, l_sc = 0;
+    int64_t l_tile = first, l_tiles_left = my_tiles;
+    auto tile_setup = [&]() {  // corpus loaders: first addresses of a row tile
+        src = reinterpret_cast<const char*>(tiles) + (unsigned long long)(l_tile * RB + lw) * (unsigned long long)KT * 1024ull;
+        const int64_t fours = (n_rb - l_tile * RB) >> 2;  // >= 1
 #pragma unroll
-        for (int l = 0; l < LA; ++l) {
-            int64_t rb = la_tile * RB + lw + 4 * l;
-            if (rb >= n_rb) rb = 0;  // row blocks past the shard: any valid tile, the epilogue masks the rows
-            a_off[l] = (unsigned long long)rb * (unsigned long long)KT * 1024ull;
-        }
+        for (int l = 1; l < 4; ++l) rel[l] = l < fours ? (unsigned)l * pstride : 0u;
     };
-    a_tile_setup();
-#pragma unroll
-    for (int l = 0; l < LB; ++l) b_off[l] = (unsigned long long)(lw + 4 * l) * (unsigned long long)KT * 1024ull;
-    auto issue_a = [&]() {  // the wave's corpus tiles of the loader's current step into its ring slot
-#pragma unroll
-        for (int l = 0; l < LA; ++l) {
-            __builtin_amdgcn_global_load_lds((hr_gptr_t)(tiles_b + a_off[l] + lane16),
-                                             (hr_lptr_t)(ringA + ((la_slot * RB) + lw + 4 * l) * kTileChunks), 16, 0,
-                                             2 /* nt: each byte is read once */);
-            a_off[l] += 1024ull;
-        }
-        if (la_kt == 0) {  // the tile's 256 row scales (64 per loader wave), needed KT steps from now
-            int64_t row = la_tile * (RB * kRowsPerBlock) + lw * 64 + lane;
+    if (loads_a) tile_setup();
+    else src = reinterpret_cast<const char*>(qfrag) + (unsigned long long)lw * (unsigned long long)KT * 1024ull;
+    auto piece = [&](int l) {  // 1 KiB of the loader's current step into its ring slot
+        __builtin_amdgcn_global_load_lds((hr_gptr_t)(src + rel[l] + lane16),
+                                         (hr_lptr_t)(ring_w + (l_slot * 16 + 4 * l) * kTileChunks), 16, 0, 0);
+    };
+    auto advance = [&]() {
+        if (loads_a && l_kt == 0) {  // the tile's 256 row scales (64 per loader wave), needed KT steps from now
+            int64_t row = l_tile * (RB * kRowsPerBlock) + lw * 64 + lane;
             if (row >= n_rb * kRowsPerBlock) row = 0;
             __builtin_amdgcn_global_load_lds((hr_gptr_t)(scale + row),
-                                             (hr_lptr_t)(reinterpret_cast<float*>(&sc_lds[la_sc][0]) + lw * 64), 4, 0, 0);
+                                             (hr_lptr_t)(reinterpret_cast<float*>(&sc_lds[l_sc][0]) + lw * 64), 4, 0, 0);
         }
-        la_slot = la_slot + 1 == DA ? 0 : la_slot + 1;
-        if (++la_kt == KT) {
-            la_kt = 0;
-            la_sc ^= 1;
-            la_tile = --la_tiles_left > 0 ? la_tile + stride : first;
-            a_tile_setup();
+        l_slot = l_slot + 1 == depth ? 0 : l_slot + 1;
+        src += 1024;
+        if (++l_kt == KT) {
+            l_kt = 0;
+            if (loads_a) {
+                l_sc ^= 1;
+                l_tile = --l_tiles_left > 0 ? l_tile + stride : first;
+                tile_setup();
+            } else {
+                src -= (unsigned long long)KT * 1024ull;  // the query fragments again, for the next row tile
+            }
         }
     };
-    auto issue_b = [&]() {  // the wave's query fragments of the query stream's current step into its ring slot
+    auto issue = [&]() {
 #pragma unroll
-        for (int l = 0; l < LB; ++l) {
-            __builtin_amdgcn_global_load_lds((hr_gptr_t)(qfrag_b + b_off[l] + lane16),
-                                             (hr_lptr_t)(ringB + ((lb_slot * GQ) + lw + 4 * l) * kTileChunks), 16, 0, 0);
-            b_off[l] += 1024ull;
-        }
-        lb_slot = lb_slot + 1 == DB ? 0 : lb_slot + 1;
-        if (++lb_kt == KT) {
-            lb_kt = 0;
-#pragma unroll
-            for (int l = 0; l < LB; ++l) b_off[l] -= (unsigned long long)KT * 1024ull;
-        }
+        for (int l = 0; l < 4; ++l) piece(l);
+        advance();
     };
     // fragments of one step: this wave's WA corpus tiles and WB query fragments (inline asm, see dense_scan_qreg_kernel)
     auto read_frags = [&](int sa, int sb, chunk_t (&a)[WA], chunk_t (&b)[WB]) {
@@ -739,58 +753,50 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
         __builtin_amdgcn_sched_barrier(0);
     };
     auto wait_landed = [&]() {  // own loads of the next step to be read have landed: only newer steps' loads were issued after them
-        if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 2) * LA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * LB) : "memory");
+        if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 2) * 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * 4) : "memory");
     };
 
-    if (loads_a) {
+    // Run-ahead before the first step: after its reads of step t the leading half (corpus loaders) refills the slot of
+    // step t - 1, the trailing half (query loaders) the slot of step t — at that point both halves have read it.
 #pragma unroll 1
-        for (int s = 0; s < DA - 1; ++s) issue_a();
-    } else {
-#pragma unroll 1
-        for (int s = 0; s < DB - 1; ++s) issue_b();
-    }
-    f32x4_t acc[WA][WB];
-#pragma unroll
-    for (int r = 0; r < WA; ++r)
-#pragma unroll
-        for (int g = 0; g < WB; ++g) acc[r][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    chunk_t a0[WA], b0[WB], a1[WA], b1[WB];  // fragments of the current / the next step
-    wait_landed();
-    lds_barrier();
-    if (loads_a) issue_a(); else issue_b();
-    read_frags(0, 0, a0, b0);
-    settle(a0, b0);
+    for (int s = 0; s < (loads_a ? DA - 1 : DB); ++s) issue();
+    f32x4_t acc[WA][WB];     // written by the first k-step of every row tile
+    chunk_t fa[WA], fb[WB];  // fragments of the step being multiplied
 
     int kt = 0, sa = 0, sb = 0;  // k-tile and ring slots of the step being multiplied
     int64_t tile = first;
     int sci = 0;
-    // One step: the first half of its MFMAs, then (data of the next step landed, barrier, refill, fragment reads of the next
-    // step into the other register set) under the second half.
-    auto step = [&](chunk_t (&ca)[WA], chunk_t (&cb)[WB], chunk_t (&na)[WA], chunk_t (&nb)[WB], bool more) {
-#pragma unroll
-        for (int r = 0; r < WA / 2; ++r)
-#pragma unroll
-            for (int g = 0; g < WB; ++g) Mfma<_Float16>::run(ca[r], cb[g], acc[r][g]);
-        const int nsa = sa + 1 == DA ? 0 : sa + 1, nsb = sb + 1 == DB ? 0 : sb + 1;
-        if (more) {
-            wait_landed();
-            lds_barrier();  // everybody's loads of the next step have landed; everybody has read this step's fragments
-            if (loads_a) issue_a(); else issue_b();
-            read_frags(nsa, nsb, na, nb);
-        }
-#pragma unroll
-        for (int r = WA / 2; r < WA; ++r)
-#pragma unroll
-            for (int g = 0; g < WB; ++g) Mfma<_Float16>::run(ca[r], cb[g], acc[r][g]);
-        if (more) settle(na, nb);
-        sa = nsa;
-        sb = nsb;
-    };
-    auto epilogue = [&]() {
+#ifdef HR_STAMP
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = __builtin_amdgcn_s_memtime();
+#endif
+    // Epilogue of a row tile.  The accumulators are not cleared here: the first k-step of a tile multiplies into zero.
+    // tail_c: the tile reaches past the shard's rows or a row mask is set (the lane's four rows of a row block are four
+    // neighbouring mask bits: one byte load per row block, all issued before the one wait).
+    auto epilogue = [&](auto tail_c) {
+        constexpr bool TAIL = decltype(tail_c)::value;
+        GEMM_STAMP(7);
         // lane holds rows quad*4..+3 of each of its WA row blocks for query (lane & 15) of each of its WB groups
         const int64_t rb0 = tile * RB + wr * WA;   // first row block of this wave
-        const bool tail = (rb0 + WA) * kRowsPerBlock > n_rows || rowmask != nullptr;
+        f32x4_t sc[WA];
+        const unsigned sc_a =
+            sc_addr + (unsigned)((sci * (RB * kRowsPerBlock / 4) + wr * WA * (kRowsPerBlock / 4) + quad) * 16);
+#pragma unroll
+        for (int r = 0; r < WA; ++r)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(sc[r]) : "v"(sc_a), "n"(r * (kRowsPerBlock / 4) * 16) : "memory");
+        unsigned ok[WA];
+        if (TAIL) {
+#pragma unroll
+            for (int r = 0; r < WA; ++r) {
+                const int64_t row0 = (rb0 + r) * kRowsPerBlock + quad * 4;
+                const int64_t left = n_rows - row0;  // how many of the lane's four rows exist
+                unsigned bits = left >= 4 ? 0xFu : left > 0 ? (1u << (int)left) - 1u : 0u;
+                if (rowmask != nullptr && left > 0) bits &= (unsigned)rowmask[row0 >> 3] >> (unsigned)(row0 & 7);
+                ok[r] = bits;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]), "+v"(sc[6]), "+v"(sc[7])::"memory");
         float m[2][WB];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
@@ -798,32 +804,14 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
             for (int g = 0; g < WB; ++g) m[h2][g] = NEG_INF;
 #pragma unroll
         for (int r = 0; r < WA; ++r) {
-            const int64_t row0 = (rb0 + r) * kRowsPerBlock + quad * 4;
-            f32x4_t sc;
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
-                         : "=v"(sc)
-                         : "v"(sc_addr + (unsigned)((sci * (RB * kRowsPerBlock / 4) + (wr * WA + r) * (kRowsPerBlock / 4) + quad) * 16))
-                         : "memory");
-            float ok[4] = {1.f, 1.f, 1.f, 1.f};
-            if (tail) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    const int64_t row = row0 + x;
-                    bool v = row < n_rows;
-                    if (v && rowmask) v = (rowmask[row >> 3] >> (row & 7)) & 1;
-                    ok[x] = v ? 1.f : 0.f;
-                }
-            }
 #pragma unroll
             for (int g = 0; g < WB; ++g) {
-                float mr = NEG_INF;
+                f32x4_t v = acc[r][g] * sc[r];
+                if (TAIL) {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) {
-                    float v = acc[r][g][x] * sc[x];
-                    v = (ok[x] != 0.f) ? v : NEG_INF;
-                    mr = fmaxf(mr, v);
+                    for (int x = 0; x < 4; ++x) v[x] = ((ok[r] >> x) & 1u) ? v[x] : NEG_INF;
                 }
-                acc[r][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                float mr = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                 if (NRB == 1) {
                     mr = fmaxf(mr, __shfl_xor(mr, 16));
                     mr = fmaxf(mr, __shfl_xor(mr, 32));
@@ -850,17 +838,62 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
         }
         tile += stride;
         sci ^= 1;
+        GEMM_STAMP(3);  // epilogue of a row tile
     };
+    // Barrier sequence (every wave passes every barrier): B2(-1) | B1(0) B2(0) | B1(1) B2(1) | ...
+    //   leading half:   [B2(s-1)] reads of step s, refill [B1(s)] MFMAs of step s, own loads of step s+1 landed [B2(s)]
+    //   trailing half:  [B1(s)]   reads of step s, refill, own loads of step s+1 landed [B2(s)] MFMAs of step s [B1(s+1)]
+    // B2(s-1) publishes "every piece of step s has landed, everybody has read step s-1"; B1 only keeps the anti-phase.
+    wait_landed();
+    lds_barrier();                 // B2(-1)
+    if (!loads_a) lds_barrier();   // B1(0): the trailing half starts half a step later
 #pragma unroll 1
-    for (int S = 0; S < total_steps; S += 2) {  // KT is even: a row tile ends after an odd step
-        step(a0, b0, a1, b1, true);                  // an even step always has a successor
-        step(a1, b1, a0, b0, S + 2 < total_steps);
-        kt += 2;
-        if (kt == KT) {
-            kt = 0;
-            epilogue();
+    for (int S = 0; S < total_steps; ++S) {
+        read_frags(sa, sb, fa, fb);
+        settle(fa, fb);
+        GEMM_STAMP(0);  // fragment reads, issue to return
+        // the refill belongs to this half-step, not between the MFMAs: a piece holds its wave for ~100 cycles wherever it
+        // is issued, and here the SIMD's other wave has the matrix pipe
+#pragma unroll
+        for (int l = 0; l < 4; ++l) piece(l);
+        advance();
+        if (!loads_a) wait_landed();
+        GEMM_STAMP(1);  // refill issue (trailing half: + own loads of the next step)
+        lds_barrier();
+        GEMM_STAMP(2);  // barrier after the reads
+        if (__builtin_expect(kt == 0, 0)) {  // first k-step of a row tile: C = 0 instead of clearing 128 registers
+#pragma unroll
+            for (int r = 0; r < WA; ++r)
+#pragma unroll
+                for (int g = 0; g < WB; ++g) {
+                    acc[r][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                    Mfma<_Float16>::run(fa[r], fb[g], acc[r][g]);
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < WA; ++r)
+#pragma unroll
+                for (int g = 0; g < WB; ++g) Mfma<_Float16>::run(fa[r], fb[g], acc[r][g]);
         }
+        GEMM_STAMP(4);  // 32 MFMAs (issue)
+        sa = sa + 1 == DA ? 0 : sa + 1;
+        sb = sb + 1 == DB ? 0 : sb + 1;
+        if (__builtin_expect(++kt == KT, 0)) {  // out of line: the k loop stays one contiguous run of code
+            kt = 0;
+            if ((tile * RB + wr * WA + WA) * kRowsPerBlock > n_rows || rowmask != nullptr) epilogue(BoolConst<true>{});
+            else epilogue(BoolConst<false>{});
+        }
+        GEMM_STAMP(7);  // bookkeeping after the MFMAs
+        if (loads_a) wait_landed();
+        GEMM_STAMP(5);  // leading half: own loads of the next step
+        lds_barrier();
+        GEMM_STAMP(6);  // barrier after the MFMAs
     }
+    if (loads_a) lds_barrier();    // the trailing half's last B1
+#ifdef HR_STAMP
+    if (blockIdx.x == 7 && lane == 0 && (wid == 0 || wid == 5))
+        for (int i = 0; i < 8; ++i) hr_gemm_stamps[wid == 0 ? 0 : 1][i] = seg[i];
+#endif
     // LDS DMA still in flight must land before the block's LDS is handed to another block
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }

@@ -1563,6 +1563,11 @@ int hr_set_profiling(hr_index* h, int enabled) {
     return HR_OK;
 }
 
+#ifdef HR_STAMP
+HR_API int hr_debug_gemm_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hbmrag::hr_gemm_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 int hr_last_kernel_ms(hr_index* h, float* out_ms, int n) {
     if (!h || !out_ms || n < 2 * PH_COUNT) return fail(h, HR_EINVAL, "need room for %d floats", 2 * PH_COUNT);
     DeviceGuard dg(h->device);
