@@ -652,6 +652,10 @@ __device__ unsigned long long hr_gemm_stamps[2][8];
 template <bool B> struct BoolConst { static constexpr bool value = B; };
 constexpr int kGemmRowBlocks = 16;               // row blocks per block tile (256 rows)
 constexpr int kGemmDA = 6, kGemmDB = 3;          // ring depth (k-steps) of the corpus / query stream
+#ifndef HR_GEMM_PIECES_L
+#define HR_GEMM_PIECES_L 4
+#endif
+constexpr int kGemmPiecesL = HR_GEMM_PIECES_L;   // refill pieces (of 4 per wave and step) issued in the read half-step; the rest go between the MFMAs
 
 template <int GQ, int NRB>                       // GQ query groups of 16 per pass: 16 (256 queries) or 8 (128)
 __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
@@ -754,7 +758,7 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     };
     auto wait_landed = [&]() {  // own loads of the next step to be read have landed: only newer steps' loads were issued after them
         if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 2) * 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * 4 + kGemmPiecesL) : "memory");
     };
 
     // Run-ahead before the first step: after its reads of step t the leading half (corpus loaders) refills the slot of
@@ -855,26 +859,37 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
         // the refill belongs to this half-step, not between the MFMAs: a piece holds its wave for ~100 cycles wherever it
         // is issued, and here the SIMD's other wave has the matrix pipe
 #pragma unroll
-        for (int l = 0; l < 4; ++l) piece(l);
-        advance();
+        for (int l = 0; l < kGemmPiecesL; ++l) piece(l);
+        if (kGemmPiecesL == 4) advance();
         if (!loads_a) wait_landed();
         GEMM_STAMP(1);  // refill issue (trailing half: + own loads of the next step)
         lds_barrier();
         GEMM_STAMP(2);  // barrier after the reads
+        auto late_piece = [&](int r) {  // the refill pieces that are not issued in the read half-step: one per 8 MFMAs
+            if (kGemmPiecesL < 4 && (r & 1) && (r >> 1) < 4 - kGemmPiecesL) {
+                piece(kGemmPiecesL + (r >> 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         if (__builtin_expect(kt == 0, 0)) {  // first k-step of a row tile: C = 0 instead of clearing 128 registers
 #pragma unroll
-            for (int r = 0; r < WA; ++r)
+            for (int r = 0; r < WA; ++r) {
 #pragma unroll
                 for (int g = 0; g < WB; ++g) {
                     acc[r][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
                     Mfma<_Float16>::run(fa[r], fb[g], acc[r][g]);
                 }
+                late_piece(r);
+            }
         } else {
 #pragma unroll
-            for (int r = 0; r < WA; ++r)
+            for (int r = 0; r < WA; ++r) {
 #pragma unroll
                 for (int g = 0; g < WB; ++g) Mfma<_Float16>::run(fa[r], fb[g], acc[r][g]);
+                late_piece(r);
+            }
         }
+        if (kGemmPiecesL < 4) advance();
         GEMM_STAMP(4);  // 32 MFMAs (issue)
         sa = sa + 1 == DA ? 0 : sa + 1;
         sb = sb + 1 == DB ? 0 : sb + 1;
