@@ -139,6 +139,8 @@ def scan_kernel_name(B: int, dim: int) -> str:
     kt = -(-(-(-dim // 32)) // 4) * 4          # 1 KiB tiles per row, padded to a multiple of 4
     if B > 128 and kt == 24:
         return "dense_scan_qreg_kernel<KT=24,GW=2,NW=8> (256 queries per pass)"
+    if B > 128 and kt >= 8:
+        return "dense_scan_gemm_kernel<GQ=16> (256 queries per pass, both operands through LDS)"
     if B > 64:
         return "dense_scan_bigq_kernel<f16,GQ=8> (128 queries per pass)"
     return "dense_scan_kernel<f16> (up to 64 queries per pass)"

@@ -412,7 +412,8 @@ def test_bench_names_the_dense_scan_kernel_per_batch():
     assert "dense_scan_kernel" in mod.scan_kernel_name(1, 768) and "dense_scan_kernel" in mod.scan_kernel_name(64, 768)
     assert "bigq" in mod.scan_kernel_name(65, 768) and "bigq" in mod.scan_kernel_name(128, 768)
     assert "qreg" in mod.scan_kernel_name(129, 768) and "qreg" in mod.scan_kernel_name(256, 700)   # 700 pads to 768
-    assert "bigq" in mod.scan_kernel_name(256, 1024) and "bigq" in mod.scan_kernel_name(256, 384)  # KT != 24
+    assert "gemm" in mod.scan_kernel_name(256, 1024) and "gemm" in mod.scan_kernel_name(256, 384)  # KT != 24, >= 8
+    assert "bigq" in mod.scan_kernel_name(256, 128) and "bigq" in mod.scan_kernel_name(128, 1024)
 
 
 def test_pmc_traffic_tool_doubles_fetch_and_filters_small_launches(tmp_path):
