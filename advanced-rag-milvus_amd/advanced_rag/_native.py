@@ -85,6 +85,8 @@ _SIGNATURES = {
     "hr_rerank_linear_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
                                         _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p,
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_add_layernorm_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
+                                            _c.c_int, _c.c_float, _c.c_void_p]),
     "hr_set_profiling": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "hr_last_kernel_ms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int]),
 }
@@ -369,6 +371,16 @@ def merge_topk_dev(d_scores: int, d_ids: int, n_lists: int, B: int, k_in: int, k
     L = load_library()
     rc = L.hr_merge_topk_dev(_vp(d_scores), _vp(d_ids), n_lists, score_stride or B * k_in, id_stride or B * k_in, B,
                              k_in, k_out, _vp(d_out_ids), _vp(d_out_scores), _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def add_layernorm_f16_dev(d_x: int, d_residual: int, d_gamma: int, d_beta: int, d_out: int, rows: int, hidden: int,
+                          eps: float, stream: int = 0):
+    """out = LayerNorm(x (+ residual)) * gamma + beta over fp16 rows (device pointers; d_residual may be 0)."""
+    L = load_library()
+    rc = L.hr_add_layernorm_f16_dev(_vp(d_x), _vp(d_residual) if d_residual else None, _vp(d_gamma), _vp(d_beta),
+                                    _vp(d_out), rows, hidden, eps, _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
 

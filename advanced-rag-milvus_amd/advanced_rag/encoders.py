@@ -6,7 +6,10 @@ and `retriever.reranker.score(pairs)` via `CrossEncoderReranker.model.predict`
 (retrieval.py:546-547, :675-678; default name cross-encoder/ms-marco-MiniLM-L-6-v2).
 These classes fill the hooks with BERT/MiniLM-shaped transformers whose GEMMs run
 on the MFMA units through PyTorch (this is the one place the north star wants
-PyTorch-ROCm rather than hand-written HIP).
+PyTorch-ROCm rather than hand-written HIP).  The one elementwise piece PyTorch
+leaves badly unfused — residual add + LayerNorm, twice per layer — goes through
+`hr_add_layernorm_f16_dev` (csrc/encoder_ops.h) when the activations are fp16 on
+the GPU; on the CPU (fp32, tests) the same expression runs in PyTorch.
 
 Offline there are no weights: models are RANDOM-INIT with a fixed seed, so
 results are structurally valid (shapes, determinism, batching, dtype) but carry
@@ -26,6 +29,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import _native
 
 _WORD = re.compile(r"\w+|[^\w\s]")
 PAD, CLS, SEP = 0, 101, 102
@@ -78,6 +83,21 @@ class HashTokenizer:
         return ids.to(device), types.to(device), (ids != PAD).to(device)
 
 
+def add_layer_norm(x: torch.Tensor, residual: Optional[torch.Tensor], ln: nn.LayerNorm) -> torch.Tensor:
+    """LayerNorm(x + residual) (residual may be None).  fp16 CUDA activations take the fused HIP kernel — one pass
+    instead of an add and a layer-norm launch; it raises if libhbmrag is missing rather than falling back."""
+    if x.is_cuda and x.dtype == torch.float16 and ln.weight.dtype == torch.float16:
+        H = x.shape[-1]
+        xc = x.contiguous()
+        rc = residual.contiguous() if residual is not None else None
+        out = torch.empty_like(xc)
+        _native.add_layernorm_f16_dev(xc.data_ptr(), rc.data_ptr() if rc is not None else 0, ln.weight.data_ptr(),
+                                      ln.bias.data_ptr(), out.data_ptr(), xc.numel() // H, H, float(ln.eps),
+                                      torch.cuda.current_stream(x.device).cuda_stream)
+        return out
+    return ln(x if residual is None else x + residual)
+
+
 class _Layer(nn.Module):
     def __init__(self, c: EncoderConfig):
         super().__init__()
@@ -93,8 +113,8 @@ class _Layer(nn.Module):
         B, T, H = x.shape
         q, k, v = self.qkv(x).view(B, T, 3, self.heads, H // self.heads).permute(2, 0, 3, 1, 4)
         a = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias)
-        x = self.ln1(x + self.out(a.transpose(1, 2).reshape(B, T, H)))  # post-LN, as BERT
-        return self.ln2(x + self.down(F.gelu(self.up(x))))
+        x = add_layer_norm(x, self.out(a.transpose(1, 2).reshape(B, T, H)), self.ln1)  # post-LN, as BERT
+        return add_layer_norm(x, self.down(F.gelu(self.up(x))), self.ln2)
 
 
 class BertEncoder(nn.Module):
@@ -109,7 +129,7 @@ class BertEncoder(nn.Module):
 
     def forward(self, ids, types, mask):
         T = ids.shape[1]
-        x = self.ln(self.word(ids) + self.pos(torch.arange(T, device=ids.device))[None] + self.seg(types))
+        x = add_layer_norm(self.word(ids) + self.pos(torch.arange(T, device=ids.device))[None], self.seg(types), self.ln)
         bias = torch.zeros(mask.shape, dtype=x.dtype, device=x.device).masked_fill(~mask, float("-inf"))[:, None, None, :]
         for layer in self.layers:
             x = layer(x, bias)

@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "dense.h"
+#include "encoder_ops.h"
 #include "fuse.h"
 #include "select.h"
 #include "sparse.h"
@@ -1378,6 +1379,32 @@ int hr_rerank_linear_dev(const int64_t* d_ids, const double* d_scores, const int
                        d_recency, k_in, base_w, method_bonus, recency_w, k_out, d_out_ids, d_out_scores, d_out_orig);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, HR_EHIP, "rerank_linear_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta, void* d_out,
+                             int64_t rows, int hidden, float eps, void* stream) {
+    if (rows < 0 || hidden <= 0 || hidden % 8 != 0) return fail(nullptr, HR_EINVAL, "hidden must be a positive multiple of 8");
+    if (hidden > 1024) return fail(nullptr, HR_ELIMIT, "hidden exceeds 1024");
+    if (!d_x || !d_gamma || !d_beta || !d_out) return fail(nullptr, HR_EINVAL, "null buffer");
+    if (((uintptr_t)d_x | (uintptr_t)d_residual | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out) & 15)
+        return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
+    if (rows == 0) return HR_OK;
+    const int chunks = hidden / 8;
+    const dim3 grid((unsigned)((rows + 15) / 16)), block(256);
+    auto* x = (const half8_t*)d_x;
+    auto* r = (const half8_t*)d_residual;
+    auto* g = (const half8_t*)d_gamma;
+    auto* b = (const half8_t*)d_beta;
+    auto* o = (half8_t*)d_out;
+    hipStream_t s = (hipStream_t)stream;
+    if (chunks <= 16) hipLaunchKernelGGL((add_layernorm_f16_kernel<1>), grid, block, 0, s, x, r, g, b, o, rows, chunks, eps);
+    else if (chunks <= 32) hipLaunchKernelGGL((add_layernorm_f16_kernel<2>), grid, block, 0, s, x, r, g, b, o, rows, chunks, eps);
+    else if (chunks <= 48) hipLaunchKernelGGL((add_layernorm_f16_kernel<3>), grid, block, 0, s, x, r, g, b, o, rows, chunks, eps);
+    else if (chunks <= 64) hipLaunchKernelGGL((add_layernorm_f16_kernel<4>), grid, block, 0, s, x, r, g, b, o, rows, chunks, eps);
+    else hipLaunchKernelGGL((add_layernorm_f16_kernel<8>), grid, block, 0, s, x, r, g, b, o, rows, chunks, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "add_layernorm_f16_kernel: %s", hipGetErrorString(e));
     return HR_OK;
 }
 

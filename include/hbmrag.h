@@ -219,6 +219,17 @@ HR_API int hr_rerank_linear_dev(const int64_t* d_ids, const double* d_scores, co
                          double method_bonus, double recency_w, int k_out, int64_t* d_out_ids,
                          double* d_out_scores, double* d_out_orig, void* stream);
 
+/* ---- encoder / cross-encoder forward: fused elementwise pieces -----------------
+ * The GEMMs and the attention of the PyTorch-ROCm encoder forwards stay with
+ * hipBLASLt / SDPA; this is the residual add + LayerNorm every post-LN BERT
+ * layer runs twice (the model class the reference's CrossEncoderReranker names,
+ * retrieval.py:651-662):  out = LayerNorm(x (+ residual)) * gamma + beta, fp16
+ * rows of `hidden` values (multiple of 8, <= 1024), fp32 statistics, one pass.
+ * All pointers are device pointers (16-byte aligned); residual may be NULL;
+ * out may alias x or residual. */
+HR_API int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
+                             void* d_out, int64_t rows, int hidden, float eps, void* stream);
+
 /* ---- measurement hooks -------------------------------------------------------
  * hr_set_profiling(1) brackets every dense-scan and sparse-scan launch with
  * HIP events on the stream it is launched on; (2) brackets all nine phases:

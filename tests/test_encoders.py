@@ -134,3 +134,56 @@ def test_device_resident_query_embedding_cache(gpu):
         RetrievalConstants.TIMEOUT_SECONDS = old
         asyncio.run(plain.close())
         asyncio.run(cached.close())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,hidden", [(1, 8), (37, 136), (1000, 384), (513, 768), (100, 1024), (16, 64)])
+def test_fused_add_layernorm_matches_torch_fp32(gpu, rows, hidden):
+    """hr_add_layernorm_f16_dev (residual add + LayerNorm in one pass, fp32 statistics) against the plain PyTorch
+    fp32 LayerNorm of the fp16-rounded sum: within fp16 output rounding (2e-3 absolute on unit-scale outputs); with and
+    without a residual, in place, rows not a multiple of the 16 a block takes."""
+    from advanced_rag import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(rows * 1000 + hidden)
+    x = (torch.randn((rows, hidden), device="cuda", generator=g) * 2).half()
+    r = torch.randn((rows, hidden), device="cuda", generator=g).half()
+    gamma = (1 + 0.1 * torch.randn(hidden, device="cuda", generator=g)).half()
+    beta = (0.1 * torch.randn(hidden, device="cuda", generator=g)).half()
+    st = torch.cuda.current_stream().cuda_stream
+    for res in (r, None):
+        s = (x + res) if res is not None else x
+        want = torch.nn.functional.layer_norm(s.float(), (hidden,), gamma.float(), beta.float(), 1e-12)
+        out = torch.empty_like(x)
+        nat.add_layernorm_f16_dev(x.data_ptr(), res.data_ptr() if res is not None else 0, gamma.data_ptr(), beta.data_ptr(),
+                                  out.data_ptr(), rows, hidden, 1e-12, st)
+        torch.cuda.synchronize()
+        assert torch.allclose(out.float(), want, atol=2e-3, rtol=2e-3), (out.float() - want).abs().max()
+    xin = x.clone()
+    nat.add_layernorm_f16_dev(xin.data_ptr(), r.data_ptr(), gamma.data_ptr(), beta.data_ptr(), xin.data_ptr(), rows, hidden,
+                              1e-12, st)   # in place
+    torch.cuda.synchronize()
+    want = torch.nn.functional.layer_norm((x + r).float(), (hidden,), gamma.float(), beta.float(), 1e-12)
+    assert torch.allclose(xin.float(), want, atol=2e-3, rtol=2e-3)
+    with pytest.raises(ValueError):
+        nat.add_layernorm_f16_dev(x.data_ptr(), 0, gamma.data_ptr(), beta.data_ptr(), x.data_ptr(), rows, 12, 1e-12, st)
+    with pytest.raises(nat.HbmRagError):
+        nat.add_layernorm_f16_dev(x.data_ptr(), 0, gamma.data_ptr(), beta.data_ptr(), x.data_ptr(), rows, 2048, 1e-12, st)
+
+
+@pytest.mark.gpu
+def test_encoder_forward_with_the_fused_layernorm_matches_the_unfused_module(gpu):
+    """The fp16 GPU forward (fused add + LayerNorm) against the same module run unfused in fp32 on the same weights."""
+    from advanced_rag.encoders import BertEncoder
+    torch.manual_seed(3)
+    c = EncoderConfig(vocab_size=2000, hidden=128, layers=2, heads=4, intermediate=256, max_len=64)
+    m32 = BertEncoder(c).cuda().eval()
+    m16 = BertEncoder(c).cuda().eval()
+    m16.load_state_dict(m32.state_dict())
+    m16 = m16.half()
+    ids = torch.randint(1, 2000, (5, 33), device="cuda")
+    types = torch.zeros_like(ids)
+    mask = torch.ones_like(ids, dtype=torch.bool)
+    mask[2, 20:] = False
+    with torch.no_grad():
+        a = m16(ids, types, mask).float()
+        b = m32(ids, types, mask)
+    assert torch.allclose(a, b, atol=3e-2, rtol=3e-2), (a - b).abs().max()
