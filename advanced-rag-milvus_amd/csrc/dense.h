@@ -652,6 +652,10 @@ __device__ unsigned long long hr_gemm_stamps[2][8];
 template <bool B> struct BoolConst { static constexpr bool value = B; };
 constexpr int kGemmRowBlocks = 16;               // row blocks per block tile (256 rows)
 constexpr int kGemmDA = 6, kGemmDB = 3;          // ring depth (k-steps) of the corpus / query stream
+#ifndef HR_GEMM_DA128
+#define HR_GEMM_DA128 7
+#endif
+constexpr int kGemmDA128 = HR_GEMM_DA128;        // corpus ring depth of the 128-query form (its query ring is half the size)
 #ifndef HR_GEMM_PIECES_L
 #define HR_GEMM_PIECES_L 4
 #endif
@@ -663,8 +667,9 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int KT, int64_t n_rows, int64_t n_super) {
     static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
     static_assert(GQ == 16 || GQ == 8, "four query quarters of 4 or 2 groups");
-    constexpr int DA = kGemmDA, DB = kGemmDB, RB = kGemmRowBlocks;
+    constexpr int DA = GQ == 16 ? kGemmDA : kGemmDA128, DB = kGemmDB, RB = kGemmRowBlocks;
     constexpr int WA = RB / 2, WB = GQ / 4;      // fragments a wave reads per step: its row blocks, its query groups
+    constexpr int PB = GQ / 4;                   // 1 KiB pieces a query loader moves per step (a corpus loader: 4)
     __shared__ chunk_t ringA[DA * RB * kTileChunks];
     __shared__ chunk_t ringB[DB * GQ * kTileChunks];
     __shared__ f32x4_t sc_lds[2][RB * kRowsPerBlock / 4];
@@ -691,10 +696,12 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     // groups further each (rel[]).  Row blocks past the shard (last tile only; row blocks come in fours) are replaced by
     // piece 0 — harmless re-reads, the epilogue masks the rows.  Past the block's last tile the corpus loader wraps to
     // its first one, which keeps the number of loads in flight fixed.
-    static_assert(RB == 16 && GQ == 16, "four pieces per step and loader wave, one ring geometry for both streams");
+    static_assert(RB == 16, "four pieces per step and corpus loader wave");
+    static_assert(kGemmPiecesL == 4 || GQ == 16, "the split refill is an experiment of the 256-query form");
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned pstride = (unsigned)KT * 4096u;   // 4 row blocks / query groups further, same k-step
     const int depth = loads_a ? DA : DB;
+    const int slot_tiles = loads_a ? RB : GQ;
     chunk_t* const ring_w = (loads_a ? ringA : ringB) + lw * kTileChunks;
     const char* src;
     unsigned rel[4] = {0u, pstride, 2u * pstride, 3u * pstride};
@@ -709,8 +716,9 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     if (loads_a) tile_setup();
     else src = reinterpret_cast<const char*>(qfrag) + (unsigned long long)lw * (unsigned long long)KT * 1024ull;
     auto piece = [&](int l) {  // 1 KiB of the loader's current step into its ring slot
-        __builtin_amdgcn_global_load_lds((hr_gptr_t)(src + rel[l] + lane16),
-                                         (hr_lptr_t)(ring_w + (l_slot * 16 + 4 * l) * kTileChunks), 16, 0, 0);
+        if (l < PB || loads_a)
+            __builtin_amdgcn_global_load_lds((hr_gptr_t)(src + rel[l] + lane16),
+                                             (hr_lptr_t)(ring_w + (l_slot * slot_tiles + 4 * l) * kTileChunks), 16, 0, 0);
     };
     auto advance = [&]() {
         if (loads_a && l_kt == 0) {  // the tile's 256 row scales (64 per loader wave), needed KT steps from now
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     };
     auto wait_landed = [&]() {  // own loads of the next step to be read have landed: only newer steps' loads were issued after them
         if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 2) * 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * 4 + kGemmPiecesL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * PB + (kGemmPiecesL < PB ? kGemmPiecesL : PB)) : "memory");
     };
 
     // Run-ahead before the first step: after its reads of step t the leading half (corpus loaders) refills the slot of

@@ -391,15 +391,16 @@ bool gemm_supported(const hr_index* h) {
     static const bool off = std::getenv("HBMRAG_NO_GEMM") != nullptr;
     return !off && h->dtype == HR_F16 && h->KT >= 8;
 }
+template <int GQ>
 hipError_t launch_scan_gemm_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
                               int nq, int64_t n_super) {
     const int64_t n_tiles = (n_super * kRowBlocksPerSuper + kGemmRowBlocks - 1) / kGemmRowBlocks;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_tiles, h->cu_count));
     if (group_rows_for(h, h->n_rows) == 16)
-        hipLaunchKernelGGL((dense_scan_gemm_kernel<16, 1>), dim3(blocks), dim3(512), 0, s, h->tiles.as<chunk_t>(), qfrag,
+        hipLaunchKernelGGL((dense_scan_gemm_kernel<GQ, 1>), dim3(blocks), dim3(512), 0, s, h->tiles.as<chunk_t>(), qfrag,
                            h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
     else
-        hipLaunchKernelGGL((dense_scan_gemm_kernel<16, 4>), dim3(blocks), dim3(512), 0, s, h->tiles.as<chunk_t>(), qfrag,
+        hipLaunchKernelGGL((dense_scan_gemm_kernel<GQ, 4>), dim3(blocks), dim3(512), 0, s, h->tiles.as<chunk_t>(), qfrag,
                            h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
     return hipGetLastError();
 }
@@ -469,6 +470,7 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     static const bool no_bigq = std::getenv("HBMRAG_NO_BIGQ") != nullptr;
     const bool big = B > 16 * Gsmall && h->KT % 4 == 0 && !no_bigq;
     static const bool prefer_gemm = std::getenv("HBMRAG_GEMM") != nullptr;
+    static const bool gemm128 = std::getenv("HBMRAG_GEMM128") != nullptr;   // 65..128 queries through the tiled-contraction form
     const bool use_qreg = qreg_supported(h) && !(prefer_gemm && gemm_supported(h));
     const bool big256 = big && B > 128 && (use_qreg || gemm_supported(h));   // 256 queries per pass
     const int Gmax = big256 ? 16 : big ? 8 : Gsmall;
@@ -504,7 +506,9 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
             hipError_t e;
             if (pass256)
                 e = use_qreg ? launch_scan_qreg_g(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
-                             : launch_scan_gemm_g(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+                             : launch_scan_gemm_g<16>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+            else if (big && gemm128 && gemm_supported(h))
+                e = launch_scan_gemm_g<8>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
             else if (big)
                 e = (h->dtype == HR_F16)
                         ? launch_scan_bigq_g<_Float16>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
