@@ -326,11 +326,17 @@ def main():
         from advanced_rag.encoders import CrossEncoderModel
         ce = CrossEncoderModel(device=str(dev), max_len=args.ce_seq_len)
         T, vocab = args.ce_seq_len, ce.config.vocab_size
+        # The rerank is per query, not per shard: with W ranks each rank scores the fused candidates of
+        # its ceil(B / W) queries and one small all-gather (5 ids + scores per query) puts the result on every rank.
+        ce_nq = -(-B // world)
+        ce_q0 = min(B, rank * ce_nq)
+        ce_q1 = min(B, ce_q0 + ce_nq)
+        ce_pairs = (ce_q1 - ce_q0) * args.top_k
         pos = torch.arange(T, device=dev, dtype=torch.int64)[None, None, :]
-        types = torch.zeros((B * args.top_k, T), dtype=torch.long, device=dev)
+        types = torch.zeros((ce_pairs, T), dtype=torch.long, device=dev)
         types[:, T // 4:] = 1
-        mask = torch.ones((B * args.top_k, T), dtype=torch.bool, device=dev)
-        ce_out = {}
+        mask = torch.ones((ce_pairs, T), dtype=torch.bool, device=dev)
+        qslot = torch.arange(ce_q0, ce_q1, device=dev)[:, None, None]
 
         ce_events = []
 
@@ -344,19 +350,31 @@ def main():
             ce_events.append((ev0, ev1))
 
         def _cross_encode(b):
-            doc = b["fused_ids"].clamp_min(0)[:, :, None]
-            toks = (1000 + (doc * 7919 + pos * 104729 + torch.arange(B, device=dev)[:, None, None] * 31) % (vocab - 1000))
-            toks = toks.view(B * args.top_k, T)
-            toks[:, 0] = 101
-            with torch.inference_mode():
-                scores = ce.module(toks, types, mask).view(B, args.top_k)
-            scores = scores.masked_fill(b["fused_ids"] < 0, float("-inf"))
-            top = torch.topk(scores, cfg.rerank_top_k, dim=1)
-            b["ce_ids"] = torch.gather(b["fused_ids"], 1, top.indices)
-            b["ce_scores"] = top.values
+            fused = b["fused_ids"][ce_q0:ce_q1]
+            ids = torch.full((ce_nq, cfg.rerank_top_k), -1, dtype=torch.int64, device=dev)
+            sc = torch.full((ce_nq, cfg.rerank_top_k), float("-inf"), dtype=torch.float32, device=dev)
+            if ce_pairs:
+                doc = fused.clamp_min(0)[:, :, None]
+                toks = (1000 + (doc * 7919 + pos * 104729 + qslot * 31) % (vocab - 1000))
+                toks = toks.view(ce_pairs, T)
+                toks[:, 0] = 101
+                with torch.inference_mode():
+                    scores = ce.module(toks, types, mask).view(ce_q1 - ce_q0, args.top_k)
+                scores = scores.float().masked_fill(fused < 0, float("-inf"))
+                top = torch.topk(scores, cfg.rerank_top_k, dim=1)
+                ids[: ce_q1 - ce_q0] = torch.gather(fused, 1, top.indices)
+                sc[: ce_q1 - ce_q0] = top.values
+            if world > 1:
+                all_ids = torch.empty((world * ce_nq, cfg.rerank_top_k), dtype=torch.int64, device="cpu" if rehearsal else dev)
+                all_sc = torch.empty((world * ce_nq, cfg.rerank_top_k), dtype=torch.float32, device="cpu" if rehearsal else dev)
+                dist.all_gather_into_tensor(all_ids, ids.cpu() if rehearsal else ids)
+                dist.all_gather_into_tensor(all_sc, sc.cpu() if rehearsal else sc)
+                ids, sc = all_ids[:B].to(dev), all_sc[:B].to(dev)
+            b["ce_ids"] = ids[:B]
+            b["ce_scores"] = sc[:B]
 
         ce_note = (f"+ cross-encoder rerank {args.top_k}->{cfg.rerank_top_k}: random-init MiniLM-L6-H384 (PyTorch-ROCm, fp16), "
-                   f"{B * args.top_k} pairs x {T} tokens per step")
+                   f"{B * args.top_k} pairs x {T} tokens per step" + (f", the queries split over the {world} ranks" if world > 1 else ""))
         if n_fly > 1:
             eng.post_hook = cross_encode
 
@@ -499,7 +517,7 @@ def main():
                          "mfma": {"achieved": mfma_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS}},
             "roofline_sparse": sparse_roof,
-            **({"cross_encoder": ce_report(ce, ce_events, B * args.top_k, args.ce_seq_len)} if args.rerank == "cross-encoder" else {}),
+            **({"cross_encoder": ce_report(ce, ce_events, ce_pairs, args.ce_seq_len)} if args.rerank == "cross-encoder" else {}),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
             "all_lists_proven_exact": flags_exact, **({"ranks_agree": ranks_agree} if ranks_agree is not None else {}),
