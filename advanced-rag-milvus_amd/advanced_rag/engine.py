@@ -378,6 +378,8 @@ class PipelinedSearchEngine(HybridSearchEngine):
         # (seen as 4.8-4.95 ms/step instead of 4.45-4.65 whenever other streams had been created first, e.g. by the
         # host-form searches of bench.py's parity gate).  Queues are per priority level, so a high-priority light
         # stream can never share one with the normal-priority heavy stream.
+        # (Swapping the priorities — scans high, finishing work normal — measures the same: 0.611 against 0.618 ms per
+        # step on a rank-sized shard, 3.83 against 3.77 ms at 10M rows.)
         self.heavy = t.cuda.Stream(self.device)
         self.light = t.cuda.Stream(self.device, priority=-1)
         self._slot_bufs = [dict() for _ in range(depth)]
