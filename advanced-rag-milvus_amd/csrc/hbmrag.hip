@@ -606,10 +606,15 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     }
     {
         Span sp(h, s, PH_SREFINE);
-        hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 255) / 256, B), dim3(256),
+        // docs per wave (HBMRAG_REFINE_DPW, 1..64): shorter chains finish this kernel sooner (0.60 -> 0.55 ms at 10M docs,
+        // 0.168 -> 0.136 ms at 1.25M with 16) but the step does not gain (3.77 -> 3.87 ms; 0.629 -> 0.619 ms): the kernel
+        // runs beside the scans, and what it takes from the HBM sooner they get later.  64 stays.
+        static const int forced_dpw = [] { const char* e = std::getenv("HBMRAG_REFINE_DPW"); return e ? std::atoi(e) : 0; }();
+        const int dpw = (forced_dpw >= 1 && forced_dpw <= 64) ? forced_dpw : 64;
+        hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 4 * dpw - 1) / (4 * dpw), B), dim3(256),
                            (size_t)kFilterBits / 8 + (size_t)stride * 8, s, h->s_indptr.as<int64_t>(),
                            h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
-                           ws->cand.as<int32_t>(), C, GR, h->n_sparse, stride, ws->cscore.as<float>(),
+                           ws->cand.as<int32_t>(), C, GR, h->n_sparse, stride, dpw, ws->cscore.as<float>(),
                            ws->crow.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
     }

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
 // The block (4 waves x 64 candidate docs of one query) stages the query in LDS
 // together with a 32768-bit hashed membership filter, so the ~99 % of entries
 // that cannot match cost one LDS read instead of a binary search.
-// Each wave walks its 64 docs one after the other with lane = entry: the doc's indices
+// Each wave walks its docs (docs_per_wave of them) one after the other with lane = entry: the doc's indices
 // and values arrive as two coalesced loads per 64 entries (the entries of the next
 // kRefinePrefetch docs are already in flight), every lane tests its own entry, and the
 // few matching products are added in ENTRY ORDER (ballot, lowest lane first), which is
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void refine_sparse_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
     const float* __restrict__ q_val, const uint8_t* __restrict__ rowmask,
-    const int32_t* __restrict__ cand, int C, int group_docs, int64_t n_docs, int q_cap,
+    const int32_t* __restrict__ cand, int C, int group_docs, int64_t n_docs, int q_cap, int docs_per_wave,
     float* __restrict__ out_score, int32_t* __restrict__ out_row) {
     // dynamic LDS: filter words, then q_cap query indices and q_cap query values (q_cap = the batch's
     // longest query rounded up, so short queries leave the CU room for many blocks)
@@ -535,9 +535,11 @@ __global__ __launch_bounds__(256) void refine_sparse_kernel(
     }
     __syncthreads();
     const int n_slots = C * group_docs;
-    const int slot0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 256 + (tid & ~63));  // first doc slot of this wave
+    // A wave's docs are a serial chain (each waits for its entries): docs_per_wave (8..64, the host's choice) trades the
+    // length of that chain against the number of blocks that rebuild the filter.
+    const int slot0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (tid >> 6)) * docs_per_wave);  // first doc slot of this wave
     if (slot0 >= n_slots) return;
-    const int n_here = min(64, n_slots - slot0);
+    const int n_here = min(docs_per_wave, n_slots - slot0);
     // lane l describes doc slot0 + l
     const int slot = slot0 + lane;
     int64_t doc = -1, p0 = 0;
