@@ -611,7 +611,8 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// 256-query scan as a tiled contraction (any KT, fp16 shards): BASELINE config 5's shape (D = 1024, B = 256).
+// 256-query scan as a tiled contraction (any KT >= 8, fp16 shards): BASELINE config 5's shape (D = 1024, B = 256).
+// (GQ = 8 is the same kernel for 65..128 queries: 64 accumulator registers per wave, half the query ring.)
 //
 // 256 queries x 1024 dims of fp16 are 512 KiB — as much as a CU's whole register file — so for this shape the queries
 // can be stationary neither in registers (dense_scan_qreg_kernel: D = 768 only) nor in LDS; two 128-query passes read
@@ -625,8 +626,8 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
 //     4 pieces of 1 KiB per wave and step): the two streams need different run-ahead (HBM: 5 steps, L2: 2) and a wave's
 //     vmcnt retires in issue order, so one wave must not carry both; every wave computes;
 //   * the two waves of a SIMD (wave w and w + 4) run half a step apart ("ping-pong"): while one issues its 32 MFMAs of
-//     a step (with its four refill pieces between them), the other does everything else — 12 fragment reads (inline
-//     asm, see dense_scan_qreg_kernel), their wait, the landed-check of its own loads.  Two LDS-only barriers per step
+//     a step, the other does everything else — 12 fragment reads (inline asm, see dense_scan_qreg_kernel), their wait,
+//     its four refill pieces, the landed-check of its own loads.  Two LDS-only barriers per step
 //     keep the halves in anti-phase.  With one barrier per step all eight waves wanted the matrix pipe at the same time
 //     and left it idle at the same time (stamp build: 40 % busy, the older wave of a SIMD waiting 600 cycles per step at
 //     the barrier for the younger one);
