@@ -652,15 +652,19 @@ __device__ unsigned long long hr_gemm_stamps[2][8];
 #endif
 template <bool B> struct BoolConst { static constexpr bool value = B; };
 constexpr int kGemmRowBlocks = 16;               // row blocks per block tile (256 rows)
-constexpr int kGemmDA = 6, kGemmDB = 3;          // ring depth (k-steps) of the corpus / query stream
+#ifndef HR_GEMM_DA
+#define HR_GEMM_DA 6
+#define HR_GEMM_DB 3
+#endif
+constexpr int kGemmDA = HR_GEMM_DA, kGemmDB = HR_GEMM_DB;  // ring depth (k-steps) of the corpus / query stream
 #ifndef HR_GEMM_DA128
 #define HR_GEMM_DA128 7
 #endif
-constexpr int kGemmDA128 = HR_GEMM_DA128;        // corpus ring depth of the 128-query form (its query ring is half the size)
-#ifndef HR_GEMM_PIECES_L
-#define HR_GEMM_PIECES_L 4
+#ifndef HR_GEMM_READ_BURST
+#define HR_GEMM_READ_BURST 3
 #endif
-constexpr int kGemmPiecesL = HR_GEMM_PIECES_L;   // refill pieces (of 4 per wave and step) issued in the read half-step; the rest go between the MFMAs
+constexpr int kGemmReadBurst = HR_GEMM_READ_BURST;  // next-step fragment reads issued together between the MFMAs
+constexpr int kGemmDA128 = HR_GEMM_DA128;        // corpus ring depth of the 128-query form (its query ring is half the size)
 
 template <int GQ, int NRB>                       // GQ query groups of 16 per pass: 16 (256 queries) or 8 (128)
 __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
@@ -698,7 +702,6 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
     // piece 0 — harmless re-reads, the epilogue masks the rows.  Past the block's last tile the corpus loader wraps to
     // its first one, which keeps the number of loads in flight fixed.
     static_assert(RB == 16, "four pieces per step and corpus loader wave");
-    static_assert(kGemmPiecesL == 4 || GQ == 16, "the split refill is an experiment of the 256-query form");
     const unsigned lane16 = (unsigned)lane * 16u;
     const unsigned pstride = (unsigned)KT * 4096u;   // 4 row blocks / query groups further, same k-step
     const int depth = loads_a ? DA : DB;
@@ -765,9 +768,11 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
         for (int g = 0; g < WB; ++g) asm volatile("" : "+v"(b[g]));
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto wait_landed = [&]() {  // own loads of the next step to be read have landed: only newer steps' loads were issued after them
+    // Own loads of the step that is read after the next barrier have landed.  Leading half, after issuing step t + DA - 1:
+    // step t + 1, so DA - 2 steps may still fly; trailing half, having issued step t + DB: step t + 2, DB - 2 steps.
+    auto wait_landed = [&]() {
         if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 2) * 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * PB + (kGemmPiecesL < PB ? kGemmPiecesL : PB)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DB - 2) * PB) : "memory");
     };
 
     // Run-ahead before the first step: after its reads of step t the leading half (corpus loaders) refills the slot of
@@ -775,7 +780,7 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
 #pragma unroll 1
     for (int s = 0; s < (loads_a ? DA - 1 : DB); ++s) issue();
     f32x4_t acc[WA][WB];     // written by the first k-step of every row tile
-    chunk_t fa[WA], fb[WB];  // fragments of the step being multiplied
+    chunk_t fa0[WA], fb0[WB], fa1[WA], fb1[WB];  // fragments of the step being multiplied / of the next one
 
     int kt = 0, sa = 0, sb = 0;  // k-tile and ring slots of the step being multiplied
     int64_t tile = first;
@@ -854,65 +859,86 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
         GEMM_STAMP(3);  // epilogue of a row tile
     };
     // Barrier sequence (every wave passes every barrier): B2(-1) | B1(0) B2(0) | B1(1) B2(1) | ...
-    //   leading half:   [B2(s-1)] reads of step s, refill [B1(s)] MFMAs of step s, own loads of step s+1 landed [B2(s)]
-    //   trailing half:  [B1(s)]   reads of step s, refill, own loads of step s+1 landed [B2(s)] MFMAs of step s [B1(s+1)]
-    // B2(s-1) publishes "every piece of step s has landed, everybody has read step s-1"; B1 only keeps the anti-phase.
-    wait_landed();
+    //   leading half:   [B2(s-1)] reads of step s returned, refill, own loads of step s+1 landed [B1(s)]
+    //                             MFMAs of step s with the reads of step s+1 between them [B2(s)]
+    //   trailing half:  [B1(s)]   reads of step s returned, refill [B2(s)]
+    //                             MFMAs of step s with the reads of step s+1 between them, own loads of step s+2 landed [B1(s+1)]
+    // B1(s) publishes "every piece of step s+1 has landed"; a ring slot is refilled only after both halves have waited
+    // for their reads of it (corpus slot of step s-1 in the leading half's read phase of step s, query slot of step s in
+    // the trailing half's).
+    auto m_phase = [&](const bool ZERO, chunk_t (&ca)[WA], chunk_t (&cb)[WB], chunk_t (&na)[WA], chunk_t (&nb)[WB], int nsa,
+                       int nsb) __attribute__((always_inline)) {
+        // ZERO (a constant at both call sites): first k-step of a row tile, C = 0 instead of clearing 128 registers
+        const unsigned aa = a_lds + (unsigned)(((nsa * RB) + wr * WA) * kTileChunks + lane) * 16u;
+        const unsigned ba = b_lds + (unsigned)(((nsb * GQ) + wq * WB) * kTileChunks + lane) * 16u;
+        // The next step's WA + WB fragments go into the other register set in bursts of kGemmReadBurst reads after every
+        // NM * kGemmReadBurst / NR MFMAs (inline asm, see dense_scan_qreg_kernel).  Measured at 12.5M x 1024: bursts of
+        // 1-2 reads per 4 MFMAs 6.17 ms, single reads spread evenly (one per 2-3 MFMAs) 6.68 ms.
+        constexpr int NR = WA + WB, NM = WA * WB, NB = (NR + kGemmReadBurst - 1) / kGemmReadBurst;  // NB bursts
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            const int r = i / WB, g = i % WB;
+            if (ZERO) acc[r][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            Mfma<_Float16>::run(ca[r], cb[g], acc[r][g]);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if ((k + 1) * NM / NB - 1 == i) {  // burst k follows this MFMA
+#pragma unroll
+                    for (int j = k * kGemmReadBurst; j < (k + 1) * kGemmReadBurst && j < NR; ++j) {
+                        if (j < WB) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(nb[j]) : "v"(ba), "n"(j * 1024) : "memory");
+                        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(na[j - WB]) : "v"(aa), "n"((j - WB) * 1024) : "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    // One k-step of a wave (a macro, not a lambda: hipcc keeps the accumulators of a lambda that calls the epilogue
+    // lambda in scratch).  ca/cb: fragments of this step; na/nb: where the next step's go.
+#define GEMM_HALF_STEP(ca, cb, na, nb)                                                                                  \
+    do {                                                                                                                \
+        settle(ca, cb);                                                                                                 \
+        GEMM_STAMP(0); /* the reads of this step, issued a half-step ago, have returned */                              \
+        /* the refill belongs to this half-step, not between the MFMAs: a piece holds its wave for ~60-100 cycles */    \
+        /* wherever it is issued, and here the SIMD's other wave has the matrix pipe */                                 \
+        piece(0);                                                                                                       \
+        piece(1);                                                                                                       \
+        piece(2);                                                                                                       \
+        piece(3);                                                                                                       \
+        advance();                                                                                                      \
+        if (loads_a) wait_landed();                                                                                     \
+        GEMM_STAMP(1); /* refill issue (leading half: + own loads of the next step) */                                  \
+        lds_barrier();                                                                                                  \
+        GEMM_STAMP(2); /* barrier before the MFMAs */                                                                   \
+        const int nsa = sa + 1 == DA ? 0 : sa + 1, nsb = sb + 1 == DB ? 0 : sb + 1;                                     \
+        if (__builtin_expect(kt == 0, 0)) m_phase(true, ca, cb, na, nb, nsa, nsb);                                      \
+        else m_phase(false, ca, cb, na, nb, nsa, nsb);                                                                  \
+        GEMM_STAMP(4); /* 32 MFMAs + 12 reads (issue) */                                                                \
+        sa = nsa;                                                                                                       \
+        sb = nsb;                                                                                                       \
+        if (__builtin_expect(++kt == KT, 0)) { /* out of line: the k loop stays one contiguous run of code */           \
+            kt = 0;                                                                                                     \
+            if ((tile * RB + wr * WA + WA) * kRowsPerBlock > n_rows || rowmask != nullptr) epilogue(BoolConst<true>{}); \
+            else epilogue(BoolConst<false>{});                                                                          \
+        }                                                                                                               \
+        GEMM_STAMP(7); /* bookkeeping after the MFMAs */                                                                \
+        if (!loads_a) wait_landed();                                                                                    \
+        GEMM_STAMP(5); /* trailing half: own loads of the step after next */                                            \
+        lds_barrier();                                                                                                  \
+        GEMM_STAMP(6); /* barrier after the MFMAs */                                                                    \
+    } while (0)
+    // steps 0 and 1 have landed (the leading half has issued one step less than wait_landed assumes)
+    if (loads_a) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DA - 3) * 4) : "memory");
+    else wait_landed();
     lds_barrier();                 // B2(-1)
+    read_frags(0, 0, fa0, fb0);
     if (!loads_a) lds_barrier();   // B1(0): the trailing half starts half a step later
 #pragma unroll 1
-    for (int S = 0; S < total_steps; ++S) {
-        read_frags(sa, sb, fa, fb);
-        settle(fa, fb);
-        GEMM_STAMP(0);  // fragment reads, issue to return
-        // the refill belongs to this half-step, not between the MFMAs: a piece holds its wave for ~100 cycles wherever it
-        // is issued, and here the SIMD's other wave has the matrix pipe
-#pragma unroll
-        for (int l = 0; l < kGemmPiecesL; ++l) piece(l);
-        if (kGemmPiecesL == 4) advance();
-        if (!loads_a) wait_landed();
-        GEMM_STAMP(1);  // refill issue (trailing half: + own loads of the next step)
-        lds_barrier();
-        GEMM_STAMP(2);  // barrier after the reads
-        auto late_piece = [&](int r) {  // the refill pieces that are not issued in the read half-step: one per 8 MFMAs
-            if (kGemmPiecesL < 4 && (r & 1) && (r >> 1) < 4 - kGemmPiecesL) {
-                piece(kGemmPiecesL + (r >> 1));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (__builtin_expect(kt == 0, 0)) {  // first k-step of a row tile: C = 0 instead of clearing 128 registers
-#pragma unroll
-            for (int r = 0; r < WA; ++r) {
-#pragma unroll
-                for (int g = 0; g < WB; ++g) {
-                    acc[r][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                    Mfma<_Float16>::run(fa[r], fb[g], acc[r][g]);
-                }
-                late_piece(r);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < WA; ++r) {
-#pragma unroll
-                for (int g = 0; g < WB; ++g) Mfma<_Float16>::run(fa[r], fb[g], acc[r][g]);
-                late_piece(r);
-            }
-        }
-        if (kGemmPiecesL < 4) advance();
-        GEMM_STAMP(4);  // 32 MFMAs (issue)
-        sa = sa + 1 == DA ? 0 : sa + 1;
-        sb = sb + 1 == DB ? 0 : sb + 1;
-        if (__builtin_expect(++kt == KT, 0)) {  // out of line: the k loop stays one contiguous run of code
-            kt = 0;
-            if ((tile * RB + wr * WA + WA) * kRowsPerBlock > n_rows || rowmask != nullptr) epilogue(BoolConst<true>{});
-            else epilogue(BoolConst<false>{});
-        }
-        GEMM_STAMP(7);  // bookkeeping after the MFMAs
-        if (loads_a) wait_landed();
-        GEMM_STAMP(5);  // leading half: own loads of the next step
-        lds_barrier();
-        GEMM_STAMP(6);  // barrier after the MFMAs
+    for (int S = 0; S < total_steps; S += 2) {  // KT is even, so is the number of steps
+        GEMM_HALF_STEP(fa0, fb0, fa1, fb1);
+        GEMM_HALF_STEP(fa1, fb1, fa0, fb0);
     }
+#undef GEMM_HALF_STEP
     if (loads_a) lds_barrier();    // the trailing half's last B1
 #ifdef HR_STAMP
     if (blockIdx.x == 7 && lane == 0 && (wid == 0 || wid == 5))

@@ -33,6 +33,8 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 for r0 in range(0, N, 500_000):
     n = min(500_000, N - r0)
     x = torch.randn((n, D), device=dev, generator=g, dtype=torch.float32).to(torch.float16); torch.cuda.synchronize()
+    if os.environ.get("PROBE_ZERO"):   # power experiment: one nonzero element per row, the MFMAs multiply zeros
+        x.zero_(); x[:, 0] = 1
     h.add_dense_dev(x.data_ptr(), n)
 h.finalize(); h.set_profiling(2)
 st = torch.cuda.current_stream().cuda_stream

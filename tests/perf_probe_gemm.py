@@ -32,9 +32,9 @@ if fn is None:
 buf = (ctypes.c_ulonglong * 16)()
 fn(buf)
 v = np.array(list(buf), dtype=np.float64).reshape(2, 8)
-names = ["fragment reads (issue to return)", "trailing half: own loads of next step", "barrier after the reads",
-         "epilogue", "32 MFMAs + refill (issue)", "leading half: own loads of next step", "barrier after the MFMAs",
-         "bookkeeping after the MFMAs"]
+names = ["reads of this step returned (settle)", "refill issue (+ leading half: own loads of next step)",
+         "barrier before the MFMAs", "epilogue", "32 MFMAs + 12 reads of the next step (issue)",
+         "trailing half: own loads of the step after next", "barrier after the MFMAs", "bookkeeping after the MFMAs"]
 steps = -(-(N // 256) // 256) * (D // 32)
 for w, label in ((0, "wave 0 (corpus loader)"), (1, "wave 5 (query loader)")):
     tot = v[w].sum()
