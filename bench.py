@@ -135,6 +135,29 @@ def pmc_traffic(rows: int, dim: int, batch: int, n_gpus: int, kernel: str = "den
     return None, None
 
 
+LAUNCHES_PER_STEP = {"dense_scan": 1, "sparse_scan": 1, "refine_dense": 1, "refine_sparse": 1, "select_groups": 2,
+                     "bucket_max": 2, "select_topk": 2}
+
+
+def step_hbm(rows: int, dim: int, batch: int, n_gpus: int, dist: str, use_sparse: bool, ms_per_step: float):
+    """HBM bytes ALL search kernels of a step move (the committed PMC passes: FETCH + WRITE per launch x launches per
+    step) over the measured step time: how full the memory system is as a whole, beside the per-kernel rooflines."""
+    total, src = 0.0, None
+    for k, n in LAUNCHES_PER_STEP.items():
+        if not use_sparse and k in ("sparse_scan", "refine_sparse"):
+            continue
+        b, path = pmc_traffic(rows, dim, batch, n_gpus, kernel=k, dist=dist)
+        if b is None:
+            if k in ("dense_scan", "sparse_scan"):
+                return None
+            continue
+        total += b * (n if use_sparse or k in ("dense_scan", "refine_dense") else n // 2)
+        src = path
+    gbps = total / (ms_per_step * 1e-3) / 1e9
+    return {"bytes_per_step": total, "achieved": gbps, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+            "frac_of_measured_copy": gbps / HBM_COPY_GBPS, "traffic_source": src}
+
+
 def scan_kernel_name(B: int, dim: int) -> str:
     """Which dense scan serves a batch of B queries (dense_search_enqueue in csrc/hbmrag.hip)."""
     kt = -(-(-(-dim // 32)) // 4) * 4          # 1 KiB tiles per row, padded to a multiple of 4
@@ -520,6 +543,7 @@ def main():
                          "mfma": {"achieved": mfma_tflops, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": mfma_tflops / MFMA_F16_PEAK_TFLOPS}},
             "roofline_sparse": sparse_roof,
+            "step_hbm": step_hbm(N, D, B, world, args.sparse_dist, use_sparse, elapsed / args.steps * 1e3),
             **({"cross_encoder": ce_report(ce, ce_events, ce_pairs, args.ce_seq_len)} if args.rerank == "cross-encoder" else {}),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},

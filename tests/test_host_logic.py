@@ -416,6 +416,26 @@ def test_bench_names_the_dense_scan_kernel_per_batch():
     assert "bigq" in mod.scan_kernel_name(256, 128) and "bigq" in mod.scan_kernel_name(128, 1024)
 
 
+def test_bench_step_hbm_sums_the_committed_pmc_traffic_of_every_search_kernel():
+    """bench.py's step_hbm block: bytes of all search kernels per step (profiles/r*_pmc_traffic*.json) over the step time;
+    only for the workloads that were profiled."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    k = json.load(open(os.path.join(root, "profiles", "r2_pmc_traffic.json")))["kernels"]
+    want = sum(k[name]["hbm_bytes_per_launch"] * n for name, n in mod.LAUNCHES_PER_STEP.items() if name in k)
+    got = mod.step_hbm(10_000_000, 768, 128, 1, "uniform", True, 4.0)
+    assert got is not None and abs(got["bytes_per_step"] - want) < 1.0
+    assert abs(got["achieved"] - want / 4.0e-3 / 1e9) < 1e-6 and got["traffic_source"].startswith("profiles/")
+    assert got["bytes_per_step"] > k["dense_scan"]["algorithmic_bytes_per_launch"]
+    assert mod.step_hbm(1_000_000, 768, 128, 1, "uniform", True, 1.0) is None     # not a profiled workload
+    c5 = mod.step_hbm(50_000_000, 1024, 256, 1, "uniform", False, 26.0)            # dense only: no sparse kernels, one select each
+    assert c5 is not None and c5["bytes_per_step"] < 1.2e11
+
+
 def test_pmc_traffic_tool_doubles_fetch_and_filters_small_launches(tmp_path):
     import importlib.util
     import json
