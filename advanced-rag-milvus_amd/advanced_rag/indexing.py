@@ -231,16 +231,22 @@ class MilvusIndexManager:
         """Boolean filter over global rows for a filter expression plus the tombstones, or None for "all rows".
         Evaluating an expression is a pass over every payload row: the result is kept per (expression, row count,
         tombstone epoch) so that repeated requests with the same filter pay for it once."""
-        if self._synthetic_rows:
-            if expr:
-                raise ValueError("filter expressions need payload columns; this shard was bulk-ingested without them")
-            return None
         n = self.num_rows
+        if self._synthetic_rows and not expr:
+            return None
         key = (expr, n, self._delete_epoch)
         if key in self._mask_cache:
             return self._mask_cache[key]
         keep = None
-        if expr:
+        if expr and self._synthetic_rows:
+            # bulk-ingested rows carry no payload columns; what their synthetic id encodes can still be filtered on:
+            # chunk_index = row % 10 (synthetic_id), derived on the fly
+            fields = {f for f, _, _ in _filters.parse(expr)}
+            if fields - {"chunk_index"}:
+                raise ValueError("this shard was bulk-ingested without payload columns: only chunk_index (= row % 10) "
+                                 f"can be filtered on, not {sorted(fields - {'chunk_index'})}")
+            keep = _filters.evaluate(expr, {"chunk_index": np.arange(n, dtype=np.int64) % 10}, n)
+        elif expr:
             keep = _filters.evaluate(expr, self._columns(), n)
         if self._deleted is not None and self._deleted[:n].any():
             alive = np.ones(n, dtype=bool)

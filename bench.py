@@ -623,6 +623,22 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
 
     lat = asyncio.run(run())
 
+    # filtered retrieve(): the expression is evaluated over every row on the first request and the boolean mask is kept
+    # per (expression, rows, tombstone epoch); every request packs and uploads N/8 bytes and the scans test the bit
+    async def run_filtered():
+        t0 = time.perf_counter()
+        out = await retr.retrieve("q0", filters={"chunk_index": {"$lt": 5}}, profile_hint="default")
+        first = (time.perf_counter() - t0) * 1e3
+        assert len(out) == args.top_k and all(int(r["id"].split("::")[1]) < 5 for r in out)
+        latf = []
+        for i in range(min(n, 50)):
+            t0 = time.perf_counter()
+            await retr.retrieve(f"q{i % flatQ.shape[0]}", filters={"chunk_index": {"$lt": 5}}, profile_hint="default")
+            latf.append((time.perf_counter() - t0) * 1e3)
+        return first, latf
+
+    first_f, lat_f = asyncio.run(run_filtered()) if world == 1 else (None, None)
+
     # the same queries through the whole public entry point, AdvancedRAGPipeline.retrieve(): query rewriting, the
     # retriever, the default rerank branch (20 -> 5), evaluation and the audit trail (SURVEY.md section 8d's latency
     # definition); its prints (SLA / risk warnings) must not reach stdout, which carries the ONE JSON line
@@ -651,7 +667,10 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
     return {"retrieve_shards": world,
             "p50_retrieve_ms": float(np.percentile(lat, 50)), "p95_retrieve_ms": float(np.percentile(lat, 95)),
             "p50_pipeline_retrieve_ms": float(np.percentile(lat2, 50)),
-            "p95_pipeline_retrieve_ms": float(np.percentile(lat2, 95)), "latency_queries": n}
+            "p95_pipeline_retrieve_ms": float(np.percentile(lat2, 95)), "latency_queries": n,
+            **({"filtered_retrieve": {"filter": "chunk_index < 5 (half of the rows)", "first_request_ms": first_f,
+                                      "p50_ms": float(np.percentile(lat_f, 50)), "p95_ms": float(np.percentile(lat_f, 95)),
+                                      "queries": len(lat_f)}} if lat_f else {})}
 
 
 if __name__ == "__main__":

@@ -504,3 +504,18 @@ def test_search_hit_formatting_matches_reference_g6():
     assert str(ei.value) == errs["sparse-bad-payload"]["message"]
     mgr.collections.clear()
     asyncio.run(mgr.close())
+
+
+def test_synthetic_payload_shards_filter_on_what_the_row_number_encodes():
+    """Bulk-ingested (payload-free) shards derive chunk_index = row % 10 for filter expressions; other fields need
+    payload columns and say so.  The mask is cached per (expression, rows, tombstone epoch)."""
+    from advanced_rag.indexing import MilvusIndexManager
+    m = MilvusIndexManager.__new__(MilvusIndexManager)
+    m._synthetic_rows, m._mask_cache, m._delete_epoch, m._deleted = 25, {}, 0, None
+    m._cols = {"id": []}
+    keep = m._row_mask("chunk_index < 3")
+    assert keep.dtype == bool and keep.tolist() == [(r % 10) < 3 for r in range(25)]
+    assert m._row_mask("chunk_index < 3") is keep                      # cached
+    assert m._row_mask(None) is None
+    with pytest.raises(ValueError, match="chunk_index"):
+        m._row_mask('doc_id == "doc1"')
