@@ -163,19 +163,27 @@ class DeviceEmbeddingTable:
         return None if s is None else self.table[s]
 
     def store(self, key: str, vec) -> Any:
+        """Rows are handed out as VIEWS (a hit is a device pointer the search kernel reads in place), so a row may only be
+        overwritten once every search already enqueued with the evicted key's view has finished: an eviction waits for the
+        device before it copies (a miss has just paid for an encoder forward; first fills of a slot need no wait).  A view
+        is valid for searches enqueued before the next store() of a new key; holders re-`lookup` after that."""
         import torch
         with self._lock:
             s = self._slots.get(key)
+            evicting = False
             if s is None:
                 if len(self._slots) >= self.capacity:
                     victim = next(iter(self._slots))
                     s = self._slots.pop(victim)
+                    evicting = True
                 else:
                     s = self._next
                     self._next += 1
                 self._slots[key] = s
-        self.table[s].copy_(torch.as_tensor(vec, dtype=torch.float32), non_blocking=True)
-        return self.table[s]
+            if evicting:
+                torch.cuda.synchronize(self.table.device)
+            self.table[s].copy_(torch.as_tensor(vec, dtype=torch.float32), non_blocking=True)
+            return self.table[s]
 
 
 _semantic_cache: Optional[EmbeddingCache] = None

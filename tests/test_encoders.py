@@ -187,3 +187,24 @@ def test_encoder_forward_with_the_fused_layernorm_matches_the_unfused_module(gpu
         a = m16(ids, types, mask).float()
         b = m32(ids, types, mask)
     assert torch.allclose(a, b, atol=3e-2, rtol=3e-2), (a - b).abs().max()
+
+
+@pytest.mark.gpu
+def test_device_embedding_table_evicts_fifo_and_keeps_values(gpu):
+    """FIFO eviction like the host cache; a row is overwritten only after the device has drained (searches enqueued with
+    the evicted key's view read the old bytes); live keys keep their slot pointer and their values."""
+    from advanced_rag.embedding_cache import DeviceEmbeddingTable
+    t = DeviceEmbeddingTable(capacity=4, dim=16, device="cuda:0")
+    vecs = {f"k{i}": torch.full((16,), float(i)) for i in range(7)}
+    views = {k: t.store(k, v) for k, v in list(vecs.items())[:4]}
+    ptrs = {k: v.data_ptr() for k, v in views.items()}
+    old_k0 = views["k0"].clone()
+    for k in ("k4", "k5", "k6"):          # evicts k0, k1, k2 in that order
+        t.store(k, vecs[k])
+    torch.cuda.synchronize()
+    assert t.lookup("k0") is None and t.lookup("k1") is None and t.lookup("k2") is None
+    assert t.lookup("k3").data_ptr() == ptrs["k3"] and torch.equal(t.lookup("k3").cpu(), vecs["k3"])
+    for k in ("k4", "k5", "k6"):
+        assert torch.equal(t.lookup(k).cpu(), vecs[k])
+    assert torch.equal(old_k0.cpu(), vecs["k0"])   # the copy taken before the eviction still holds k0's bytes
+    assert t.store("k5", vecs["k5"]).data_ptr() == t.lookup("k5").data_ptr()   # re-store of a live key: same slot
