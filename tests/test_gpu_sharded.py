@@ -100,13 +100,15 @@ def test_sharded_manager_equals_single_shard(gpu, long_timeout):
         asyncio.run(three.close())
 
 
-def test_g5_reference_runs_on_two_shards(gpu, long_timeout):
-    """The reference's own retrieve() outputs (golden g5) through a manager whose rows sit on two shards."""
+@pytest.mark.parametrize("n_shards", [2, 8])
+def test_g5_reference_runs_on_two_and_eight_shards(gpu, long_timeout, n_shards):
+    """The reference's own retrieve() outputs (golden g5) through a manager whose rows sit on two shards, and on eight
+    (BASELINE config 4's shard count; all of them on the one GPU of the test box)."""
     from test_gpu_golden import _g5_manager, _run_g5
     g, X, csr, Q, SQ = g5_data.inputs()
-    mgr = _g5_manager("float32", X, csr, True, devices=[0, 0])
+    mgr = _g5_manager("float32", X, csr, True, devices=[0] * n_shards)
     try:
-        assert mgr._main.n_shards == 2 and min(len(r) for r in mgr._main.rows_of) == 500
+        assert mgr._main.n_shards == n_shards and min(len(r) for r in mgr._main.rows_of) == 1000 // n_shards
         for run in (r for r in g["runs"] if r["with_sparse"]):
             out = _run_g5(mgr, Q, SQ, run)
             assert [o["id"] for o in out] == run["ids"]
