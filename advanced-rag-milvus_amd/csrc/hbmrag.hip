@@ -410,18 +410,41 @@ int max_groups_for_dim(const hr_index* h) {
     return std::max(1, std::min(4, g));
 }
 
-// Two-level candidate selection: per-bucket maxima, then one block per query.
-int launch_group_select(hr_index* h, Workspace* ws, hipStream_t s, int B, int64_t n_groups, int C) {
+// Two-level candidate selection: per-bucket maxima, then one block per query — for one modality or for both
+// modalities of a hybrid search in one pair of launches (select.h: GroupSelPair).
+int group_sel_args(hr_index* h, Workspace* ws, int B, int64_t n_groups, int C, GroupSelArgs* a) {
     const int64_t n_buckets = (n_groups + kBucketGroups - 1) / kBucketGroups;
     HIP_TRY(h, ws->bmax.ensure((size_t)B * n_buckets * sizeof(float)));
-    if (n_groups > C && n_buckets > C) {
-        hipLaunchKernelGGL(bucket_max_kernel, dim3((unsigned)((n_buckets + 4 * kBucketsPerWave - 1) / (4 * kBucketsPerWave)), B),
-                           dim3(256), 0, s,
-                           ws->gmax.as<float>(), n_groups, n_buckets, ws->bmax.as<float>());
+    a->gmax = ws->gmax.as<float>();
+    a->bmax = ws->bmax.as<float>();
+    a->n_groups = n_groups;
+    a->n_buckets = n_buckets;
+    a->C = C;
+    a->two_level = n_groups > C && n_buckets > C;
+    a->cand = ws->cand.as<int32_t>();
+    a->a_cut = ws->acut.as<float>();
+    return HR_OK;
+}
+int launch_group_select_pair(hr_index* h, hipStream_t s, int B, const GroupSelPair& p) {
+    int64_t blocks = 0;
+    for (int m = 0; m < p.n; ++m)
+        if (p.m[m].two_level) blocks = std::max(blocks, (p.m[m].n_buckets + 4 * kBucketsPerWave - 1) / (4 * kBucketsPerWave));
+    if (blocks > 0) {
+        hipLaunchKernelGGL(bucket_max_kernel, dim3((unsigned)blocks, B, p.n), dim3(256), 0, s, p);
         HIP_TRY(h, hipGetLastError());
     }
-    hipLaunchKernelGGL(select_groups_kernel, dim3(B), dim3(1024), 0, s, ws->gmax.as<float>(), ws->bmax.as<float>(),
-                       n_groups, n_buckets, C, ws->cand.as<int32_t>(), ws->acut.as<float>());
+    hipLaunchKernelGGL(select_groups_kernel, dim3(B, p.n), dim3(1024), 0, s, p);
+    HIP_TRY(h, hipGetLastError());
+    return HR_OK;
+}
+int launch_group_select(hr_index* h, Workspace* ws, hipStream_t s, int B, int64_t n_groups, int C) {
+    GroupSelPair p{};
+    p.n = 1;
+    HR_TRY(group_sel_args(h, ws, B, n_groups, C, &p.m[0]));
+    return launch_group_select_pair(h, s, B, p);
+}
+int launch_topk_pair(hr_index* h, hipStream_t s, int B, const TopkPair& p) {
+    hipLaunchKernelGGL(select_topk_kernel, dim3(B, p.n), dim3(1024), 0, s, p);
     HIP_TRY(h, hipGetLastError());
     return HR_OK;
 }
@@ -452,6 +475,84 @@ void dense_eps(const hr_index* h, float* eps_abs, int* norm_mode) {
         *eps_abs = (float)(unit * (double)h->max_row_norm * 1.0001);
         *norm_mode = 1;
     }
+}
+
+// ---- finishing steps shared by the single-modality chains and the hybrid chain --------------------------------
+int launch_refine_dense(hr_index* h, Workspace* ws, hipStream_t s, const float* d_q, int B, int C, int GR,
+                        const uint8_t* d_mask) {
+    const int cosine = h->metric == HR_METRIC_COSINE;
+    if (h->dtype == HR_F16)
+        hipLaunchKernelGGL((refine_dense_kernel<_Float16>), dim3((C * GR + 63) / 64, B), dim3(64), 0, s,
+                           h->tiles.as<chunk_t>(), h->KT, (int)h->dim, d_q, ws->qn2.as<double>(),
+                           h->norm2.as<double>(), d_mask, ws->cand.as<int32_t>(), C, GR, h->n_rows, cosine,
+                           ws->cscore.as<float>(), ws->crow.as<int32_t>());
+    else
+        hipLaunchKernelGGL((refine_dense_kernel<float>), dim3((C * GR + 63) / 64, B), dim3(64), 0, s,
+                           h->tiles.as<chunk_t>(), h->KT, (int)h->dim, d_q, ws->qn2.as<double>(),
+                           h->norm2.as<double>(), d_mask, ws->cand.as<int32_t>(), C, GR, h->n_rows, cosine,
+                           ws->cscore.as<float>(), ws->crow.as<int32_t>());
+    HIP_TRY(h, hipGetLastError());
+    return HR_OK;
+}
+TopkArgs dense_topk_args(const hr_index* h, Workspace* ws, int C, int GR, int k, int64_t* d_ids, float* d_scores,
+                         int32_t* d_flags) {
+    float eps_abs;
+    int norm_mode;
+    dense_eps(h, &eps_abs, &norm_mode);
+    TopkArgs a{};
+    a.cscore = ws->cscore.as<float>();
+    a.crow = ws->crow.as<int32_t>();
+    a.n = C * GR;
+    a.K = k;
+    a.row_offset = h->row_offset;
+    a.a_cut = ws->acut.as<float>();
+    a.cut_floor = -INFINITY;
+    a.eps_abs = eps_abs;
+    a.eps_abs_q = nullptr;
+    a.eps_rel = 0.0f;
+    a.norm_mode = norm_mode;
+    a.qn2 = ws->qn2.as<double>();
+    a.out_ids = d_ids;
+    a.out_scores = d_scores;
+    a.flags = d_flags;
+    return a;
+}
+int launch_refine_sparse(hr_index* h, Workspace* ws, hipStream_t s, const int64_t* d_qptr, const int32_t* d_qidx,
+                         const float* d_qval, int B, int C, int GR, int stride, const uint8_t* d_mask) {
+    // docs per wave (HBMRAG_REFINE_DPW, 1..64): shorter chains finish this kernel sooner (0.60 -> 0.55 ms at 10M docs,
+    // 0.168 -> 0.136 ms at 1.25M with 16) but the step does not gain (3.77 -> 3.87 ms; 0.629 -> 0.619 ms): the kernel
+    // runs beside the scans, and what it takes from the HBM sooner they get later.  64 stays.
+    static const int forced_dpw = [] { const char* e = std::getenv("HBMRAG_REFINE_DPW"); return e ? std::atoi(e) : 0; }();
+    const int dpw = (forced_dpw >= 1 && forced_dpw <= 64) ? forced_dpw : 64;
+    hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 4 * dpw - 1) / (4 * dpw), B), dim3(256),
+                       (size_t)kFilterBits / 8 + (size_t)stride * 8, s, h->s_indptr.as<int64_t>(),
+                       h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
+                       ws->cand.as<int32_t>(), C, GR, h->n_sparse, stride, dpw, ws->cscore.as<float>(),
+                       ws->crow.as<int32_t>());
+    HIP_TRY(h, hipGetLastError());
+    return HR_OK;
+}
+TopkArgs sparse_topk_args(const hr_index* h, Workspace* ws, int C, int GR, int k, int64_t* d_ids, float* d_scores,
+                          int32_t* d_flags) {
+    // scan error = fixed-point rounding ((nnz+1)/scale per query, from the prep kernel) + fp32 rounding of w*scale, of
+    // the product and of the int->float conversion (relative, 2^-22 with margin).
+    TopkArgs a{};
+    a.cscore = ws->cscore.as<float>();
+    a.crow = ws->crow.as<int32_t>();
+    a.n = C * GR;
+    a.K = k;
+    a.row_offset = h->row_offset;
+    a.a_cut = ws->acut.as<float>();
+    a.cut_floor = 0.0f;
+    a.eps_abs = 0.0f;
+    a.eps_abs_q = ws->qeps.as<float>();
+    a.eps_rel = (float)(std::ldexp(1.0, -11) * 1.01 + std::ldexp(1.0, -22));  // fp16 posting weights
+    a.norm_mode = 0;
+    a.qn2 = nullptr;
+    a.out_ids = d_ids;
+    a.out_scores = d_scores;
+    a.flags = d_flags;
+    return a;
 }
 
 // Enqueue a complete dense search on stream s.  All pointers are device pointers.
@@ -528,29 +629,14 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     }
     {
         Span sp(h, s, PH_REFINE);
-        const int cosine = h->metric == HR_METRIC_COSINE;
-        if (h->dtype == HR_F16)
-            hipLaunchKernelGGL((refine_dense_kernel<_Float16>), dim3((C * GR + 63) / 64, B), dim3(64), 0, s,
-                               h->tiles.as<chunk_t>(), h->KT, (int)h->dim, d_q, ws->qn2.as<double>(),
-                               h->norm2.as<double>(), d_mask, ws->cand.as<int32_t>(), C, GR, h->n_rows, cosine,
-                               ws->cscore.as<float>(), ws->crow.as<int32_t>());
-        else
-            hipLaunchKernelGGL((refine_dense_kernel<float>), dim3((C * GR + 63) / 64, B), dim3(64), 0, s,
-                               h->tiles.as<chunk_t>(), h->KT, (int)h->dim, d_q, ws->qn2.as<double>(),
-                               h->norm2.as<double>(), d_mask, ws->cand.as<int32_t>(), C, GR, h->n_rows, cosine,
-                               ws->cscore.as<float>(), ws->crow.as<int32_t>());
-        HIP_TRY(h, hipGetLastError());
+        HR_TRY(launch_refine_dense(h, ws, s, d_q, B, C, GR, d_mask));
     }
     {
         Span sp(h, s, PH_TOPK);
-        float eps_abs;
-        int norm_mode;
-        dense_eps(h, &eps_abs, &norm_mode);
-        hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, s, ws->cscore.as<float>(),
-                           ws->crow.as<int32_t>(), C * GR, k, h->row_offset, ws->acut.as<float>(),
-                           -INFINITY, eps_abs, (const float*)nullptr, 0.0f, norm_mode, ws->qn2.as<double>(), d_ids,
-                           d_scores, d_flags);
-        HIP_TRY(h, hipGetLastError());
+        TopkPair p{};
+        p.n = 1;
+        p.m[0] = dense_topk_args(h, ws, C, GR, k, d_ids, d_scores, d_flags);
+        HR_TRY(launch_topk_pair(h, s, B, p));
     }
     return HR_OK;
 }
@@ -606,28 +692,59 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     }
     {
         Span sp(h, s, PH_SREFINE);
-        // docs per wave (HBMRAG_REFINE_DPW, 1..64): shorter chains finish this kernel sooner (0.60 -> 0.55 ms at 10M docs,
-        // 0.168 -> 0.136 ms at 1.25M with 16) but the step does not gain (3.77 -> 3.87 ms; 0.629 -> 0.619 ms): the kernel
-        // runs beside the scans, and what it takes from the HBM sooner they get later.  64 stays.
-        static const int forced_dpw = [] { const char* e = std::getenv("HBMRAG_REFINE_DPW"); return e ? std::atoi(e) : 0; }();
-        const int dpw = (forced_dpw >= 1 && forced_dpw <= 64) ? forced_dpw : 64;
-        hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 4 * dpw - 1) / (4 * dpw), B), dim3(256),
-                           (size_t)kFilterBits / 8 + (size_t)stride * 8, s, h->s_indptr.as<int64_t>(),
-                           h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
-                           ws->cand.as<int32_t>(), C, GR, h->n_sparse, stride, dpw, ws->cscore.as<float>(),
-                           ws->crow.as<int32_t>());
-        HIP_TRY(h, hipGetLastError());
+        HR_TRY(launch_refine_sparse(h, ws, s, d_qptr, d_qidx, d_qval, B, C, GR, stride, d_mask));
     }
     {
         Span sp(h, s, PH_STOPK);
-        // scan error = fixed-point rounding ((nnz+1)/scale per query, from the prep
-        // kernel) + fp32 rounding of w*scale, of the product and of the int->float
-        // conversion (relative, 2^-22 with margin).
-        const float eps_rel = (float)(std::ldexp(1.0, -11) * 1.01 + std::ldexp(1.0, -22));  // fp16 posting weights
-        hipLaunchKernelGGL(select_topk_kernel, dim3(B), dim3(1024), 0, s, ws->cscore.as<float>(),
-                           ws->crow.as<int32_t>(), C * GR, k, h->row_offset, ws->acut.as<float>(), 0.0f, 0.0f,
-                           ws->qeps.as<float>(), eps_rel, 0, (const double*)nullptr, d_ids, d_scores, d_flags);
-        HIP_TRY(h, hipGetLastError());
+        TopkPair p{};
+        p.n = 1;
+        p.m[0] = sparse_topk_args(h, ws, C, GR, k, d_ids, d_scores, d_flags);
+        HR_TRY(launch_topk_pair(h, s, B, p));
+    }
+    return HR_OK;
+}
+
+// Finishing chain of a hybrid search (both modalities non-empty): the same kernels as the two single chains, with the
+// selection steps of both modalities in one launch each — 5 dependent launches (+ 2 refines) instead of 8.
+// The profiling spans of the merged launches are booked on the dense phases (group_select, topk).
+int hybrid_finish_enqueue(hr_index* h, Workspace* wd, Workspace* wsp, hipStream_t s, const float* d_q,
+                          const int64_t* d_qptr, const int32_t* d_qidx, const float* d_qval, int B, int max_q_nnz, int k,
+                          const uint8_t* d_mask, int64_t* d_ids, float* d_scores, int32_t* d_flags, int64_t* s_ids,
+                          float* s_scores, int32_t* s_flags, int C) {
+    const int GRd = group_rows_for(h, h->n_rows), GRs = group_rows_for(h, h->n_sparse);
+    const int64_t n_super = (h->n_rows + kSuperRows - 1) / kSuperRows;
+    const int64_t ng_d = n_super * (kSuperRows / GRd), ng_s = (h->n_sparse + GRs - 1) / GRs;
+    const int stride = (int)round_up(std::max(max_q_nnz, 1), 64);
+    for (Workspace* ws : {wd, wsp}) {
+        const int GR = ws == wd ? GRd : GRs;
+        HIP_TRY(h, ws->cand.ensure((size_t)B * C * sizeof(int32_t)));
+        HIP_TRY(h, ws->acut.ensure((size_t)B * sizeof(float)));
+        HIP_TRY(h, ws->cscore.ensure((size_t)B * C * GR * sizeof(float)));
+        HIP_TRY(h, ws->crow.ensure((size_t)B * C * GR * sizeof(int32_t)));
+    }
+    {
+        Span sp(h, s, PH_GSEL);
+        GroupSelPair p{};
+        p.n = 2;
+        HR_TRY(group_sel_args(h, wd, B, ng_d, C, &p.m[0]));
+        HR_TRY(group_sel_args(h, wsp, B, ng_s, C, &p.m[1]));
+        HR_TRY(launch_group_select_pair(h, s, B, p));
+    }
+    {
+        Span sp(h, s, PH_REFINE);
+        HR_TRY(launch_refine_dense(h, wd, s, d_q, B, C, GRd, d_mask));
+    }
+    {
+        Span sp(h, s, PH_SREFINE);
+        HR_TRY(launch_refine_sparse(h, wsp, s, d_qptr, d_qidx, d_qval, B, C, GRs, stride, d_mask));
+    }
+    {
+        Span sp(h, s, PH_TOPK);
+        TopkPair p{};
+        p.n = 2;
+        p.m[0] = dense_topk_args(h, wd, C, GRd, k, d_ids, d_scores, d_flags);
+        p.m[1] = sparse_topk_args(h, wsp, C, GRs, k, s_ids, s_scores, s_flags);
+        HR_TRY(launch_topk_pair(h, s, B, p));
     }
     return HR_OK;
 }
@@ -1336,6 +1453,10 @@ int hr_hybrid_finish_dev(hr_index* h, const float* d_q, const int64_t* d_q_indpt
     int64_t* s_ids = d_ids + (size_t)B * k;
     float* s_scores = d_scores + (size_t)B * k;
     int32_t* s_flags = d_flags ? d_flags + B : nullptr;
+    static const bool split_chains = std::getenv("HBMRAG_SPLIT_FINISH") != nullptr;  // A/B: the two chains one after the other
+    if (h->n_rows > 0 && h->n_sparse > 0 && !split_chains)
+        return hybrid_finish_enqueue(h, wd, wsp, s, d_q, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, d_ids,
+                                     d_scores, d_flags, s_ids, s_scores, s_flags, C);
     if (h->n_rows > 0)
         HR_TRY(dense_search_enqueue(h, wd, s, d_q, B, k, d_rowmask, d_ids, d_scores, d_flags, C, nullptr, PHASE_FINISH));
     else

@@ -103,18 +103,38 @@ __device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, Select
 // issues all of their (coalesced, 256-byte) loads before the first reduction, so the pass streams the
 // table of group maxima instead of paying one round trip per bucket.
 constexpr int kBucketsPerWave = 8;
-__global__ __launch_bounds__(256) void bucket_max_kernel(const float* __restrict__ gmax, int64_t n_groups,
-                                                         int64_t n_buckets, float* __restrict__ bmax) {
+
+// The selection kernels take their arguments per MODALITY (dense list, sparse list): the two finishing chains of a hybrid
+// search are independent and each of these launches covers only B blocks, so the hybrid path issues ONE launch for both
+// (blockIdx.y / .z = modality) instead of two in a row — three dependent launches less on the stream that finishes a
+// batch.  Single-modality searches pass n = 1.
+struct GroupSelArgs {
+    const float* gmax;    // [B][n_groups] group maxima of the scan
+    float* bmax;          // [B][n_buckets] level-2 maxima (written by bucket_max_kernel when two_level)
+    int64_t n_groups, n_buckets;
+    int C;                // candidate groups per query
+    int two_level;        // n_groups > C && n_buckets > C
+    int32_t* cand;        // [B][C] out
+    float* a_cut;         // [B] out
+};
+struct GroupSelPair {
+    GroupSelArgs m[2];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void bucket_max_kernel(GroupSelPair p) {
+    const GroupSelArgs& a = p.m[blockIdx.z];
+    if (!a.two_level) return;
     const int q = blockIdx.y;
     const int lane = threadIdx.x & 63;
     const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * kBucketsPerWave;
-    if (b0 >= n_buckets) return;
-    const float* gm = gmax + (int64_t)q * n_groups;
+    if (b0 >= a.n_buckets) return;
+    const float* gm = a.gmax + (int64_t)q * a.n_groups;
     float v[kBucketsPerWave];
 #pragma unroll
     for (int i = 0; i < kBucketsPerWave; ++i) {
         const int64_t g = (b0 + i) * kBucketGroups + lane;
-        v[i] = g < n_groups ? gm[g] : -__builtin_inff();
+        v[i] = g < a.n_groups ? gm[g] : -__builtin_inff();
     }
     float mine = -__builtin_inff();
 #pragma unroll
@@ -122,7 +142,7 @@ __global__ __launch_bounds__(256) void bucket_max_kernel(const float* __restrict
         const float m = wave_max(v[i]);
         if (lane == i) mine = m;
     }
-    if (lane < kBucketsPerWave && b0 + lane < n_buckets) bmax[(int64_t)q * n_buckets + b0 + lane] = mine;
+    if (lane < kBucketsPerWave && b0 + lane < a.n_buckets) a.bmax[(int64_t)q * a.n_buckets + b0 + lane] = mine;
 }
 
 // One block per query.  gmax[q][n_groups] (+ bmax[q][n_buckets]) -> cand[q][C]
@@ -130,13 +150,16 @@ __global__ __launch_bounds__(256) void bucket_max_kernel(const float* __restrict
 // of every row OUTSIDE the candidate groups (-inf when every group is a
 // candidate).  Groups outside the selected buckets are bounded by the best
 // unselected bucket maximum, groups inside them by the (C+1)-th candidate key.
-__global__ __launch_bounds__(1024) void select_groups_kernel(const float* __restrict__ gmax,
-                                                             const float* __restrict__ bmax, int64_t n_groups,
-                                                             int64_t n_buckets, int C,
-                                                             int32_t* __restrict__ cand,
-                                                             float* __restrict__ a_cut) {
+__global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelPair p) {
     __shared__ SelectScratch sh;
     __shared__ int32_t sel_bucket[HR_MAX_TOPK * 2];  // C <= k + k/2 rounded to 16 (<= 400)
+    const GroupSelArgs& a = p.m[blockIdx.y];
+    const float* __restrict__ gmax = a.gmax;
+    const float* __restrict__ bmax = a.bmax;
+    const int64_t n_groups = a.n_groups, n_buckets = a.n_buckets;
+    const int C = a.C;
+    int32_t* __restrict__ cand = a.cand;
+    float* __restrict__ a_cut = a.a_cut;
     const int q = blockIdx.x;
     const float* gm = gmax + (int64_t)q * n_groups;
     int32_t* out = cand + (int64_t)q * C;
@@ -194,14 +217,42 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(const float* __rest
 //   a_cut by more than the scan's error bound.
 // norm_mode: 0 = scores compare to a_cut as they are; 1 = divide by |q| first
 // (inner-product metric: the scan works on the unit-normalised query).
-__global__ __launch_bounds__(1024) void select_topk_kernel(
-    const float* __restrict__ cscore, const int32_t* __restrict__ crow, int n, int K,
-    int64_t row_offset, const float* __restrict__ a_cut, float cut_floor, float eps_abs,
-    const float* __restrict__ eps_abs_q, float eps_rel, int norm_mode, const double* __restrict__ qn2,
-    int64_t* __restrict__ out_ids,
-    float* __restrict__ out_scores, int32_t* __restrict__ flags) {
+struct TopkArgs {
+    const float* cscore;   // [B][n] canonical candidate scores
+    const int32_t* crow;   // [B][n] candidate rows (< 0 = invalid)
+    int n, K;
+    int64_t row_offset;
+    const float* a_cut;
+    float cut_floor, eps_abs;
+    const float* eps_abs_q;
+    float eps_rel;
+    int norm_mode;
+    const double* qn2;
+    int64_t* out_ids;
+    float* out_scores;
+    int32_t* flags;
+};
+struct TopkPair {
+    TopkArgs m[2];
+    int n;
+};
+
+__global__ __launch_bounds__(1024) void select_topk_kernel(TopkPair p) {
     __shared__ SelectScratch sh;
     __shared__ uint64_t sel[HR_MAX_TOPK];
+    const TopkArgs& a = p.m[blockIdx.y];
+    const float* __restrict__ cscore = a.cscore;
+    const int32_t* __restrict__ crow = a.crow;
+    const int n = a.n, K = a.K;
+    const int64_t row_offset = a.row_offset;
+    const float* __restrict__ a_cut = a.a_cut;
+    const float cut_floor = a.cut_floor, eps_abs = a.eps_abs, eps_rel = a.eps_rel;
+    const float* __restrict__ eps_abs_q = a.eps_abs_q;
+    const int norm_mode = a.norm_mode;
+    const double* __restrict__ qn2 = a.qn2;
+    int64_t* __restrict__ out_ids = a.out_ids;
+    float* __restrict__ out_scores = a.out_scores;
+    int32_t* __restrict__ flags = a.flags;
     const int q = blockIdx.x;
     const float* cs = cscore + (int64_t)q * n;
     const int32_t* cr = crow + (int64_t)q * n;

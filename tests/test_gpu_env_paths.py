@@ -52,7 +52,8 @@ CHILD = textwrap.dedent("""
 """)
 
 
-@pytest.mark.parametrize("env", [{"HBMRAG_GEMM128": "1", "HBMRAG_GEMM": "1"}, {"HBMRAG_REFINE_DPW": "8", "HBMRAG_NO_QREG": "1"}])
+@pytest.mark.parametrize("env", [{"HBMRAG_GEMM128": "1", "HBMRAG_GEMM": "1"},
+                                 {"HBMRAG_REFINE_DPW": "8", "HBMRAG_NO_QREG": "1", "HBMRAG_SPLIT_FINISH": "1"}])
 def test_opt_in_kernel_variants_match_the_oracle(gpu, env):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT)], env=e, capture_output=True, text=True, timeout=600)
