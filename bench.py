@@ -135,15 +135,15 @@ def pmc_traffic(rows: int, dim: int, batch: int, n_gpus: int, kernel: str = "den
     return None, None
 
 
-LAUNCHES_PER_STEP = {"dense_scan": 1, "sparse_scan": 1, "refine_dense": 1, "refine_sparse": 1, "select_groups": 2,
-                     "bucket_max": 2, "select_topk": 2}
+# search kernels of a step; each is launched once (the selection kernels cover both modalities of a hybrid step in one launch)
+STEP_KERNELS = ("dense_scan", "sparse_scan", "refine_dense", "refine_sparse", "select_groups", "bucket_max", "select_topk")
 
 
 def step_hbm(rows: int, dim: int, batch: int, n_gpus: int, dist: str, use_sparse: bool, ms_per_step: float):
-    """HBM bytes ALL search kernels of a step move (the committed PMC passes: FETCH + WRITE per launch x launches per
-    step) over the measured step time: how full the memory system is as a whole, beside the per-kernel rooflines."""
+    """HBM bytes ALL search kernels of a step move (the committed PMC passes: FETCH + WRITE per launch, one launch of
+    each per step) over the measured step time: how full the memory system is as a whole, beside the per-kernel rooflines."""
     total, src = 0.0, None
-    for k, n in LAUNCHES_PER_STEP.items():
+    for k in STEP_KERNELS:
         if not use_sparse and k in ("sparse_scan", "refine_sparse"):
             continue
         b, path = pmc_traffic(rows, dim, batch, n_gpus, kernel=k, dist=dist)
@@ -151,7 +151,7 @@ def step_hbm(rows: int, dim: int, batch: int, n_gpus: int, dist: str, use_sparse
             if k in ("dense_scan", "sparse_scan"):
                 return None
             continue
-        total += b * (n if use_sparse or k in ("dense_scan", "refine_dense") else n // 2)
+        total += b
         src = path
     gbps = total / (ms_per_step * 1e-3) / 1e9
     return {"bytes_per_step": total, "achieved": gbps, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,

@@ -426,7 +426,7 @@ def test_bench_step_hbm_sums_the_committed_pmc_traffic_of_every_search_kernel():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     k = json.load(open(os.path.join(root, "profiles", "r2_pmc_traffic.json")))["kernels"]
-    want = sum(k[name]["hbm_bytes_per_launch"] * n for name, n in mod.LAUNCHES_PER_STEP.items() if name in k)
+    want = sum(k[name]["hbm_bytes_per_launch"] for name in mod.STEP_KERNELS if name in k)
     got = mod.step_hbm(10_000_000, 768, 128, 1, "uniform", True, 4.0)
     assert got is not None and abs(got["bytes_per_step"] - want) < 1.0
     assert abs(got["achieved"] - want / 4.0e-3 / 1e9) < 1e-6 and got["traffic_source"].startswith("profiles/")
