@@ -41,7 +41,8 @@ def oracle_pipeline(X, ptr, idx, val, Q, SQ, cfg):
 
 
 @pytest.mark.parametrize("n,d,V,nnz,B,top_k", [(6000, 128, 800, 12, 9, 20), (20000, 768, 10000, 100, 64, 20),
-                                                (300, 64, 100, 5, 3, 50)])
+                                                (300, 64, 100, 5, 3, 50),
+                                                (60000, 256, 2000, 30, 70, 100)])   # k' = 200 = HR_MAX_TOPK, C = 304 groups
 def test_engine_single_shard_matches_oracle(gpu, n, d, V, nnz, B, top_k):
     X, ptr, idx, val, Q, SQ = corpus(n, d, V, nnz, B, seed=n)
     h = nat.ShardHandle(d, nat.HR_F16, nat.HR_METRIC_COSINE, V)
