@@ -17,9 +17,10 @@ HR_F32, HR_F16 = 0, 1
 HR_METRIC_IP, HR_METRIC_COSINE = 0, 1
 HR_METHOD_SEMANTIC, HR_METHOD_SPARSE, HR_METHOD_DOMAIN = 1, 2, 4
 HR_MAX_TOPK = 256
-HR_N_PHASES = 9
+HR_N_PHASES = 10
 PHASE_NAMES = ("prep", "dense_scan", "group_select", "refine", "topk",
-               "sparse_scan", "sparse_select", "sparse_refine", "sparse_topk")
+               "sparse_scan", "sparse_select", "sparse_refine", "sparse_topk", "finish_fused")
+HR_DEBUG_FINISH_MODE, HR_DEBUG_FAIL_NEXT_BUILD, HR_DEBUG_DENSE_KERNELS, HR_DEBUG_SPARSE_RPB, HR_DEBUG_GROUP_ROWS = 1, 2, 3, 4, 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhbmrag.so")
@@ -72,6 +73,8 @@ _SIGNATURES = {
     "hr_search_hybrid_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
                                         _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                         _c.c_void_p, _c.c_void_p]),
+    "hr_hybrid_prep_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
+                                      _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "hr_hybrid_scan_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
                                       _c.c_int64, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p]),
     "hr_hybrid_finish_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
@@ -82,6 +85,11 @@ _SIGNATURES = {
                                    _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "hr_merge_topk_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
                                      _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_post_lists_dev": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p]),
+    "hr_stream_create": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.POINTER(_c.c_void_p)]),
+    "hr_stream_destroy": (_c.c_int, [_c.c_int, _c.c_void_p]),
+    "hr_set_scan_cus": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "hr_debug_option": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int]),
     "hr_rerank_linear_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int,
                                         _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p,
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p]),
@@ -319,6 +327,13 @@ class ShardHandle:
                                                    _vp(d_rowmask) if d_rowmask else None, _vp(d_ids), _vp(d_scores),
                                                    _vp(d_flags) if d_flags else None, _vp(stream) if stream else None))
 
+    def hybrid_prep_dev(self, d_q: int, d_indptr: int, d_idx: int, d_val: int, B: int, nnz_total: int, max_q_nnz: int,
+                        k: int, slot: int, stream: int = 0):
+        """Query preparation of `slot` alone, on `stream`; the next hybrid_scan_dev on the slot enqueues the scans only."""
+        self._check(self._lib.hr_hybrid_prep_dev(self._h, _vp(d_q), _vp(d_indptr), _vp(d_idx) if d_idx else None,
+                                                 _vp(d_val) if d_val else None, B, nnz_total, max_q_nnz, k, slot,
+                                                 _vp(stream) if stream else None))
+
     def hybrid_scan_dev(self, d_q: int, d_indptr: int, d_idx: int, d_val: int, B: int, nnz_total: int, max_q_nnz: int,
                         k: int, slot: int, stream: int = 0, d_rowmask: int = 0):
         self._check(self._lib.hr_hybrid_scan_dev(self._h, _vp(d_q), _vp(d_indptr), _vp(d_idx) if d_idx else None,
@@ -333,6 +348,13 @@ class ShardHandle:
                                                    _vp(d_rowmask) if d_rowmask else None, slot, _vp(d_ids),
                                                    _vp(d_scores), _vp(d_flags) if d_flags else None,
                                                    _vp(stream) if stream else None))
+
+    def set_scan_cus(self, n_cus: int):
+        """Compute units the scans' stream may occupy (0 = all): sizes their persistent grids (hr_stream_create masks)."""
+        self._check(self._lib.hr_set_scan_cus(self._h, int(n_cus)))
+
+    def debug_option(self, key: int, value: int):
+        self._check(self._lib.hr_debug_option(self._h, key, value))
 
     # -- measurement
     def set_profiling(self, level: int):
@@ -373,6 +395,64 @@ def merge_topk_dev(d_scores: int, d_ids: int, n_lists: int, B: int, k_in: int, k
                              k_in, k_out, _vp(d_out_ids), _vp(d_out_scores), _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
+
+
+class PostArgs(ctypes.Structure):
+    """hr_post_args of include/hbmrag.h, field for field."""
+    _fields_ = [
+        ("ids", _c.c_void_p * 3), ("scores", _c.c_void_p * 3), ("k_in", _c.c_int32 * 3), ("k_fuse", _c.c_int32 * 3),
+        ("n_lists", _c.c_int32), ("rrf_k", _c.c_int32), ("id_stride", _c.c_int64), ("score_stride", _c.c_int64),
+        ("merged_ids", _c.c_void_p * 3), ("merged_scores", _c.c_void_p * 3), ("w", _c.c_double * 3),
+        ("fused_ids", _c.c_void_p), ("fused_scores", _c.c_void_p), ("fused_methods", _c.c_void_p),
+        ("fused_n", _c.c_void_p), ("top_k", _c.c_int32), ("rerank", _c.c_int32), ("base_w", _c.c_double),
+        ("method_bonus", _c.c_double), ("recency_w", _c.c_double), ("recency", _c.c_void_p), ("k_out", _c.c_int32),
+        ("reserved", _c.c_int32), ("rr_ids", _c.c_void_p), ("rr_scores", _c.c_void_p), ("rr_orig", _c.c_void_p),
+        ("flags", _c.c_void_p), ("flag_stride", _c.c_int64), ("n_flag_rows", _c.c_int32), ("reserved2", _c.c_int32),
+        ("agg_flags", _c.c_void_p),
+    ]
+
+
+def post_lists_dev(args: PostArgs, B: int, stream: int = 0):
+    """[merge of every modality's exchanged lists] -> RRF -> [learned-ranker rerank] in one launch."""
+    L = load_library()
+    rc = L.hr_post_lists_dev(ctypes.byref(args), B, _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def debug_option(key: int, value: int):
+    L = load_library()
+    rc = L.hr_debug_option(None, key, value)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def stream_create(device: int = 0, priority: int = 0, cu_mask: Optional[Sequence[int]] = None) -> int:
+    """A HIP stream (raw handle) with a priority or, when `cu_mask` (32-bit words, bit i = CU i) is given, confined to
+    those compute units.  Wrap it with torch.cuda.ExternalStream; release it with stream_destroy."""
+    L = load_library()
+    out = ctypes.c_void_p()
+    words = np.ascontiguousarray(cu_mask, dtype=np.uint32) if cu_mask is not None else None
+    rc = L.hr_stream_create(device, priority, _vp(words) if words is not None else None,
+                            0 if words is None else int(words.shape[0]), ctypes.byref(out))
+    if rc != 0:
+        _raise_global(L, rc)
+    return int(out.value)
+
+
+def stream_destroy(device: int, stream: int):
+    L = load_library()
+    rc = L.hr_stream_destroy(device, _vp(stream))
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def cu_mask_words(n_cus_total: int, lo: int, hi: int):
+    """32-bit mask words with bits [lo, hi) set out of n_cus_total."""
+    words = np.zeros((n_cus_total + 31) // 32, dtype=np.uint32)
+    for i in range(lo, hi):
+        words[i >> 5] |= np.uint32(1 << (i & 31))
+    return words
 
 
 def add_layernorm_f16_dev(d_x: int, d_residual: int, d_gamma: int, d_beta: int, d_out: int, rows: int, hidden: int,

@@ -153,7 +153,8 @@ class EngineConfig:
 
 class HybridSearchEngine:
     def __init__(self, handle: "nat.ShardHandle", config: Optional[EngineConfig] = None, process_group=None,
-                 device: Optional[str] = None, stream=None, domain_handle: "Optional[nat.ShardHandle]" = None):
+                 device: Optional[str] = None, stream=None, domain_handle: "Optional[nat.ShardHandle]" = None,
+                 simulate_ranks: int = 0):
         import torch
         self.torch = torch
         self.h = handle
@@ -168,6 +169,10 @@ class HybridSearchEngine:
             self.dist = torch.distributed
             self.world = self.dist.get_world_size(process_group)
             self.rank = self.dist.get_rank(process_group)
+        # simulate_ranks = W > 1 on ONE process: the post-exchange work of a W-rank step (merge of W lists per
+        # modality) is put on the finishing stream without a collective — a projection aid for benchmarks
+        self.simulate_ranks = int(simulate_ranks) if self.world == 1 and simulate_ranks and simulate_ranks > 1 else 0
+        self.n_lists = self.simulate_ranks or self.world
         self.device = torch.device(device or f"cuda:{handle.device}")
         # Optional private stream: several engines on different streams keep several query batches
         # in flight, so the latency-bound tail of one batch (select / refine / exchange / fuse)
@@ -207,8 +212,11 @@ class HybridSearchEngine:
             b["dom_ids"] = t.full((B, cfg.top_k), -1, dtype=t.int64, device=dev)
             b["dom_scores"] = t.zeros((B, cfg.top_k), dtype=t.float32, device=dev)
             b["dom_flags"] = t.ones((B,), dtype=t.int32, device=dev)
-        if self.world > 1:
-            b["gathered"] = t.empty((self.world, layout.nbytes), dtype=t.uint8, device=dev)
+        if self.n_lists > 1:
+            b["gathered"] = t.empty((self.n_lists, layout.nbytes), dtype=t.uint8, device=dev)
+            b["agg_flags_buf"] = t.ones((n_mod, B), dtype=t.int32, device=dev)
+            if self.simulate_ranks:  # copy r of the local lists carries ids shifted by r * 2^40
+                b["sim_shift"] = (t.arange(self.n_lists, dtype=t.int64, device=dev) << 40).view(-1, 1)
             b["m_ids"] = t.empty((n_main, B, kp), dtype=t.int64, device=dev)
             b["m_scores"] = t.empty((n_main, B, kp), dtype=t.float32, device=dev)
             if self.hd is not None:
@@ -231,7 +239,7 @@ class HybridSearchEngine:
         self.hd.search_dense_dev(domain_q.data_ptr(), B, cfg.top_k, b["dom_ids"].data_ptr(), b["dom_scores"].data_ptr(),
                                  b["dom_flags"].data_ptr(), 0, stream)
         b["flags"][m].copy_(b["dom_flags"])
-        if self.world > 1:
+        if self.n_lists > 1:
             b["ids"][m, :, :cfg.top_k].copy_(b["dom_ids"])
             b["scores"][m, :, :cfg.top_k].copy_(b["dom_scores"])
 
@@ -263,41 +271,70 @@ class HybridSearchEngine:
         self._search_domain(b, domain_q, B, stream)
         return self._post_lists(b, B, stream)
 
+    def _post_args(self, b: dict, B: int, n_lists: int, gathered) -> "nat.PostArgs":
+        """hr_post_args of one buffer set: built once per (buffer set, use of the domain list) and reused."""
+        key = ("post_args", n_lists, b["use_domain"])
+        a = b.get(key)
+        if a is not None:
+            return a
+        cfg, kp, lay = self.cfg, b["kp"], b["layout"]
+        a = nat.PostArgs()
+        mods = [(0, 0, kp)]                                   # (fusion slot, modality in the pack, entries fused)
+        if cfg.use_sparse:
+            mods.append((1, 1, kp))
+        if b["use_domain"]:
+            mods.append((2, b["n_mod"] - 1, cfg.top_k))
+        for slot, m, k_fuse in mods:
+            a.k_fuse[slot] = k_fuse
+            if n_lists > 1:
+                sc_off, id_off, sc_stride, id_stride = lay.merge_args(m)
+                a.ids[slot], a.scores[slot], a.k_in[slot] = gathered.data_ptr() + id_off, gathered.data_ptr() + sc_off, kp
+                a.id_stride, a.score_stride = id_stride, sc_stride
+                mi, ms = (b["m_dom_ids"], b["m_dom_scores"]) if slot == 2 else (b["m_ids"][m], b["m_scores"][m])
+                a.merged_ids[slot], a.merged_scores[slot] = mi.data_ptr(), ms.data_ptr()
+            elif slot == 2:
+                a.ids[slot], a.k_in[slot] = b["dom_ids"].data_ptr(), cfg.top_k
+            else:
+                a.ids[slot], a.k_in[slot] = b["ids"][m].data_ptr(), kp
+        a.n_lists, a.rrf_k, a.top_k = n_lists, cfg.rrf_k, cfg.top_k
+        a.w[0], a.w[1], a.w[2] = cfg.dense_weight, cfg.sparse_weight, cfg.domain_weight
+        a.fused_ids, a.fused_scores = b["fused_ids"].data_ptr(), b["fused_scores"].data_ptr()
+        a.fused_methods, a.fused_n = b["fused_methods"].data_ptr(), b["fused_n"].data_ptr()
+        a.rerank = 1 if cfg.enable_reranking else 0
+        a.base_w, a.method_bonus, a.recency_w, a.k_out = cfg.base_weight, cfg.method_bonus, cfg.recency_weight, cfg.rerank_top_k
+        a.rr_ids, a.rr_scores, a.rr_orig = b["rr_ids"].data_ptr(), b["rr_scores"].data_ptr(), b["rr_orig"].data_ptr()
+        if n_lists > 1:  # the flags travelled with the lists: their minimum over the ranks comes out of the same launch
+            a.flags = gathered.data_ptr() + lay.id_bytes + lay.score_bytes
+            a.flag_stride, a.n_flag_rows = lay.nbytes // 4, lay.n_mod * lay.B
+            a.agg_flags = b["agg_flags_buf"].data_ptr()
+        b[key] = a
+        return a
+
+    def _exchange(self, b: dict):
+        """The per-rank lists of this batch from every rank: one all-gather (or, for `simulate_ranks`, a device copy
+        that stands in for it: the local lists replicated with their ids shifted per copy, so that the merge does the
+        work of a real W-rank step on one GPU — timing only, the merged lists mean nothing)."""
+        if self.simulate_ranks:
+            g = b["gathered"]
+            g.copy_(b["pack"].unsqueeze(0).expand(self.n_lists, -1))
+            ids_all = g[:, : b["layout"].id_bytes].view(self.torch.int64).view(self.n_lists, -1)
+            ids_all += b["sim_shift"] * (ids_all >= 0)
+            return g
+        return exchange_lists(b["pack"], self.world, self.dist, self.group, out=b["gathered"])
+
     def _post_lists(self, b: dict, B: int, stream: int) -> dict:
-        """Everything after the per-shard lists exist: [exchange + merge] -> RRF -> rerank."""
-        cfg, kp = self.cfg, b["kp"]
+        """Everything after the per-shard lists exist: [exchange] -> ONE launch for merge + RRF + rerank."""
         ids, scores = b["ids"], b["scores"]
-        dom = b["use_domain"]
-        dom_ids = b.get("dom_ids")
-        if self.world > 1:
-            g = exchange_lists(b["pack"], self.world, self.dist, self.group, out=b["gathered"])
-            for m in range(b["n_main"]):
-                sc_off, id_off, sc_stride, id_stride = b["layout"].merge_args(m)
-                nat.merge_topk_dev(g.data_ptr() + sc_off, g.data_ptr() + id_off, self.world, B, kp, kp,
-                                   b["m_ids"][m].data_ptr(), b["m_scores"][m].data_ptr(), stream,
-                                   score_stride=sc_stride, id_stride=id_stride)
+        g = None
+        if self.n_lists > 1:
+            g = self._exchange(b)
             ids, scores = b["m_ids"], b["m_scores"]
-            if dom:
-                sc_off, id_off, sc_stride, id_stride = b["layout"].merge_args(b["n_mod"] - 1)
-                nat.merge_topk_dev(g.data_ptr() + sc_off, g.data_ptr() + id_off, self.world, B, kp, cfg.top_k,
-                                   b["m_dom_ids"].data_ptr(), b["m_dom_scores"].data_ptr(), stream,
-                                   score_stride=sc_stride, id_stride=id_stride)
-                dom_ids = b["m_dom_ids"]
             # a list is proven iff every rank proved its part: identical on all ranks, so they all take the same
-            # repair decision (resolve_inexact)
-            b["agg_flags"] = b["layout"].flags_view(g).amin(dim=0)
+            # repair decision (resolve_inexact); the minimum over the ranks is taken by the post kernel
+            b["agg_flags"] = b["agg_flags_buf"]
         else:
             b["agg_flags"] = b["flags"]
-        nat.fuse_rrf_dev(ids[0].data_ptr(), kp, ids[1].data_ptr() if cfg.use_sparse else 0,
-                         kp if cfg.use_sparse else 0, dom_ids.data_ptr() if dom else 0, cfg.top_k if dom else 0, B,
-                         cfg.dense_weight, cfg.sparse_weight, cfg.domain_weight, cfg.rrf_k,
-                         cfg.top_k, b["fused_ids"].data_ptr(), b["fused_scores"].data_ptr(),
-                         b["fused_methods"].data_ptr(), b["fused_n"].data_ptr(), stream)
-        if cfg.enable_reranking:
-            nat.rerank_linear_dev(b["fused_ids"].data_ptr(), b["fused_scores"].data_ptr(),
-                                  b["fused_methods"].data_ptr(), b["fused_n"].data_ptr(), B, cfg.top_k,
-                                  cfg.base_weight, cfg.method_bonus, cfg.recency_weight, cfg.rerank_top_k,
-                                  b["rr_ids"].data_ptr(), b["rr_scores"].data_ptr(), b["rr_orig"].data_ptr(), stream)
+        nat.post_lists_dev(self._post_args(b, B, self.n_lists, g), B, stream)
         b["list_ids"], b["list_scores"] = ids, scores
         return b
 
@@ -364,8 +401,10 @@ class PipelinedSearchEngine(HybridSearchEngine):
     """
 
     def __init__(self, handle, config: Optional[EngineConfig] = None, process_group=None, device: Optional[str] = None,
-                 depth: int = 2, domain_handle=None):
-        super().__init__(handle, config, process_group, device, domain_handle=domain_handle)
+                 depth: int = 2, domain_handle=None, simulate_ranks: int = 0, light_cus: int = 0,
+                 prep_stream: bool = True):
+        super().__init__(handle, config, process_group, device, domain_handle=domain_handle,
+                         simulate_ranks=simulate_ranks)
         if not self.cfg.use_sparse:
             raise ValueError("PipelinedSearchEngine needs the sparse modality")
         if not 1 <= depth <= 4:
@@ -380,8 +419,32 @@ class PipelinedSearchEngine(HybridSearchEngine):
         # stream can never share one with the normal-priority heavy stream.
         # (Swapping the priorities — scans high, finishing work normal — measures the same: 0.611 against 0.618 ms per
         # step on a rank-sized shard, 3.83 against 3.77 ms at 10M rows.)
-        self.heavy = t.cuda.Stream(self.device)
-        self.light = t.cuda.Stream(self.device, priority=-1)
+        #
+        # A third stream (PREP) carries the query preparation of every batch (fragment-order queries, |q|^2, the sparse
+        # queries' fixed-point scale): a handful of short, nearly empty launches that would otherwise sit between the
+        # scans on the heavy stream and leave the chip idle there (~25 us of a 0.6 ms step on a rank-sized shard).
+        #
+        # light_cus > 0 confines the finishing + prep streams to the first `light_cus` compute units and the scans to
+        # the rest (hr_stream_create CU masks; the scans' persistent grids are sized to their share).
+        self._raw_streams = []
+        self.light_cus = int(light_cus)
+        if self.light_cus > 0:
+            n_cu = t.cuda.get_device_properties(self.device).multi_processor_count
+            if not 0 < self.light_cus < n_cu:
+                raise ValueError(f"light_cus must be in (0, {n_cu})")
+            di = self.device.index or 0
+            low, high = nat.cu_mask_words(n_cu, 0, self.light_cus), nat.cu_mask_words(n_cu, self.light_cus, n_cu)
+            self._raw_streams = [nat.stream_create(di, 0, high), nat.stream_create(di, 0, low), nat.stream_create(di, 0, low)]
+            self.heavy, self.light, self.prep = (t.cuda.ExternalStream(r, device=self.device) for r in self._raw_streams)
+            for hh in (self.h, self.hd):
+                if hh is not None:
+                    hh.set_scan_cus(n_cu - self.light_cus)
+        else:
+            self.heavy = t.cuda.Stream(self.device)
+            self.light = t.cuda.Stream(self.device, priority=-1)
+            self.prep = t.cuda.Stream(self.device, priority=-1) if prep_stream else None
+        if not prep_stream:
+            self.prep = None
         self._slot_bufs = [dict() for _ in range(depth)]
         self._n = 0
         # optional callable(buffers) run on the light stream after fusion/rerank of every batch, before the
@@ -396,6 +459,7 @@ class PipelinedSearchEngine(HybridSearchEngine):
             self._bufs.pop(B, None)
             t = self.torch
             b["scan_done"] = t.cuda.Event()
+            b["prep_done"] = t.cuda.Event()
             b["done"] = t.cuda.Event()
             b["done"].record(t.cuda.current_stream(self.device))
             self._slot_bufs[slot][B] = b
@@ -412,7 +476,14 @@ class PipelinedSearchEngine(HybridSearchEngine):
         kp = b["kp"]
         indptr, idx, val, max_nnz = sparse
         nnz = int(idx.shape[0])
-        self.heavy.wait_event(b["done"])  # the batch that used this slot before has been finished
+        if self.prep is not None:
+            self.prep.wait_event(b["done"])  # the batch that used this slot before has been finished
+            self.h.hybrid_prep_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, nnz, int(max_nnz),
+                                   kp, slot, self.prep.cuda_stream)
+            b["prep_done"].record(self.prep)
+            self.heavy.wait_event(b["prep_done"])
+        else:
+            self.heavy.wait_event(b["done"])
         self.h.hybrid_scan_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, nnz, int(max_nnz),
                                kp, slot, self.heavy.cuda_stream)
         with t.cuda.stream(self.heavy):
@@ -430,8 +501,22 @@ class PipelinedSearchEngine(HybridSearchEngine):
         return b
 
     def synchronize(self):
+        if self.prep is not None:
+            self.prep.synchronize()
         self.heavy.synchronize()
         self.light.synchronize()
+
+    def close(self):
+        """Release the masked streams (if any) and give the scans the whole device back."""
+        self.synchronize()
+        if self._raw_streams:
+            for hh in (self.h, self.hd):
+                if hh is not None:
+                    hh.set_scan_cus(0)
+            raw, self._raw_streams = self._raw_streams, []
+            self.heavy = self.light = self.prep = None
+            for r in raw:
+                nat.stream_destroy(self.device.index or 0, r)
 
     def all_flags_exact(self) -> bool:
         return all(bool(b["agg_flags"].min().item() == 1) for slot in self._slot_bufs for b in slot.values()

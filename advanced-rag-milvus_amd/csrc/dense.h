@@ -952,28 +952,18 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
 // Canonical refine: 64 candidate rows per wave (group_rows = 16 or 64 rows per candidate group); lane = row.
 // score = (float) S with S the k-ordered fp64 sum of exact products.  The same
 // arithmetic is restated in oracle/oracle.c:dense_score().
+// One candidate row slot of query qi: returns false (invalid) or the canonical score and the row.
 template <typename STORE>
-__global__ __launch_bounds__(64) void refine_dense_kernel(
-    const chunk_t* __restrict__ tiles, int KT, int dim, const float* __restrict__ q,
-    const double* __restrict__ qn2, const double* __restrict__ norm2,
-    const uint8_t* __restrict__ rowmask, const int32_t* __restrict__ cand, int C, int group_rows,
-    int64_t n_rows, int cosine, float* __restrict__ out_score, int32_t* __restrict__ out_row) {
+__device__ inline bool refine_dense_slot(const chunk_t* __restrict__ tiles, int KT, int dim, const float* __restrict__ qq,
+                                         double qn2_q, const double* __restrict__ norm2,
+                                         const uint8_t* __restrict__ rowmask, const int32_t* cand_q, int group_rows,
+                                         int64_t n_rows, int cosine, int slot, float* score, int32_t* row_out) {
     constexpr int EPC = kChunkBytes / (int)sizeof(STORE);
-    const int qi = blockIdx.y, lane = threadIdx.x;
-    const int slot = blockIdx.x * 64 + lane;          // candidate row slot of this query
-    const int n_slots = C * group_rows;
-    if (slot >= n_slots) return;
-    const int32_t group = cand[(int64_t)qi * C + slot / group_rows];
-    const int64_t o = (int64_t)qi * n_slots + slot;
+    const int32_t group = cand_q[slot / group_rows];
     const int64_t row = (int64_t)group * group_rows + slot % group_rows;
     bool valid = group >= 0 && row < n_rows;
     if (valid && rowmask) valid = (rowmask[row >> 3] >> (row & 7)) & 1;
-    if (!valid) {  // whole-wave exit is fine: no cross-lane ops below
-        out_score[o] = -__builtin_inff();
-        out_row[o] = -1;
-        return;
-    }
-    const float* qq = q + (int64_t)qi * dim;
+    if (!valid) return false;
     double s = 0.0;
     // The fp64 add chain is serial by definition (canonical k order); the loads are not:
     // fetch one whole 1 KiB-tile row slice (4 chunks) x 2 tiles per round trip.
@@ -992,11 +982,34 @@ __global__ __launch_bounds__(64) void refine_dense_kernel(
         }
     }
     if (cosine) {
-        double d = norm2[row] * qn2[qi];
+        double d = norm2[row] * qn2_q;
         s = (d > 0.0) ? s / sqrt(d) : 0.0;
     }
-    out_score[o] = (float)s;
-    out_row[o] = (int32_t)row;
+    *score = (float)s;
+    *row_out = (int32_t)row;
+    return true;
+}
+
+template <typename STORE>
+__global__ __launch_bounds__(64) void refine_dense_kernel(
+    const chunk_t* __restrict__ tiles, int KT, int dim, const float* __restrict__ q,
+    const double* __restrict__ qn2, const double* __restrict__ norm2,
+    const uint8_t* __restrict__ rowmask, const int32_t* __restrict__ cand, int C, int group_rows,
+    int64_t n_rows, int cosine, float* __restrict__ out_score, int32_t* __restrict__ out_row) {
+    const int qi = blockIdx.y, lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;          // candidate row slot of this query
+    const int n_slots = C * group_rows;
+    if (slot >= n_slots) return;
+    const int64_t o = (int64_t)qi * n_slots + slot;
+    float sc = -__builtin_inff();
+    int32_t row = -1;
+    if (!refine_dense_slot<STORE>(tiles, KT, dim, q + (int64_t)qi * dim, qn2[qi], norm2, rowmask, cand + (int64_t)qi * C,
+                                  group_rows, n_rows, cosine, slot, &sc, &row)) {
+        sc = -__builtin_inff();
+        row = -1;
+    }
+    out_score[o] = sc;
+    out_row[o] = row;
 }
 
 }  // namespace hbmrag

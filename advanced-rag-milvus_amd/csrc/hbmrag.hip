@@ -24,6 +24,7 @@
 #include "common.h"
 #include "dense.h"
 #include "encoder_ops.h"
+#include "finish.h"
 #include "fuse.h"
 #include "select.h"
 #include "sparse.h"
@@ -76,10 +77,12 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Phase { PH_PREP = 0, PH_SCAN, PH_GSEL, PH_REFINE, PH_TOPK, PH_SSCAN, PH_SGSEL, PH_SREFINE, PH_STOPK, PH_COUNT };
+enum Phase { PH_PREP = 0, PH_SCAN, PH_GSEL, PH_REFINE, PH_TOPK, PH_SSCAN, PH_SGSEL, PH_SREFINE, PH_STOPK, PH_FINISH, PH_COUNT };
+static_assert(PH_COUNT == HR_N_PHASES, "phase table and ABI out of step");
 
 struct Workspace {
     std::mutex mu;                 // held while one call enqueues: calls sharing a workspace must not interleave their kernels
+    int users = 0;                 // calls that hold or wait for this workspace (guarded by hr_index::pool_mu): never pruned while > 0
     hipStream_t stream = nullptr;  // own stream (host-form calls)
     hipStream_t side = nullptr;    // side stream + events of hr_search_hybrid_dev
     hipEvent_t ev_scan = nullptr, ev_side = nullptr;
@@ -119,7 +122,7 @@ struct hr_index {
     int64_t dim = 0, sparse_dim = 0;
     int dtype = HR_F16, metric = HR_METRIC_COSINE;
     int KT = 0;  // 1 KiB tiles per row block along k
-    int group_rows_override = 0;  // HBMRAG_GROUP_ROWS=16|64 pins the candidate-group size (default: by shard size)
+    int group_rows_override = 0;  // hr_debug_option(HR_DEBUG_GROUP_ROWS) at creation pins the candidate-group size (default: by shard size)
     int64_t row_offset = 0;
 
     // dense shard
@@ -134,7 +137,8 @@ struct hr_index {
     std::vector<int32_t> pend_idx;
     std::vector<float> pend_val;
     std::vector<int64_t> h_range_base{0};  // first posting of every range's block (+ total), host copy
-    int64_t n_sparse = 0, n_sparse_built = 0, nnz_built = 0;
+    // n_sparse rows added; n_csr / nnz_csr of them in the device CSR; n_sparse_built of them in the postings
+    int64_t n_sparse = 0, n_csr = 0, nnz_csr = 0, n_sparse_built = 0;
     float max_sparse_abs = 0.f;  // max |doc weight|: bounds the scan's fixed-point range
     DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post;  // post: packed (fp16 weight | u16 accumulator slot)
     DevBuf idle_post;  // 64 x 4 idle postings: what scan lanes with nothing to fetch read (sparse.h)
@@ -143,6 +147,9 @@ struct hr_index {
     bool finalized = false;
     int profiling = 0;
     int cu_count = 256;
+    int scan_cus = 0;              // compute units the scans' stream may use (hr_set_scan_cus); 0 = all
+    int fault_inject = 0;          // hr_debug_inject_fault: fail the next build_sparse after its CSR upload (tests)
+    bool slot_prepped[HR_MAX_SLOTS] = {};  // hr_hybrid_prep_dev has prepared the slot's queries for the next scan
 
     mutable std::shared_mutex rw;  // searches shared, add/finalize exclusive
     std::mutex pool_mu;
@@ -224,33 +231,57 @@ void give_ws(hr_index* h, Workspace* w) {
 }
 // The workspace of a caller-owned stream, returned LOCKED: `*_dev` calls that share a stream share its workspace
 // (query fragments, group maxima, candidates), so one call's enqueue must not interleave with another's — their
-// kernels then run in stream order.  The map is pruned when it grows: a long-lived handle used from many short-lived
-// streams would otherwise keep every stream's buffers for ever.
+// kernels then run in stream order.  The handle-wide pool lock is held only for the map lookup: a call that waits for a
+// busy workspace (its owner may be inside hipMalloc) does not stall the other streams of the handle.  The map is
+// pruned when it grows — a long-lived handle used from many short-lived streams would otherwise keep every stream's
+// buffers for ever — and the pruned workspaces are freed after the pool lock is dropped (hipFree synchronises the device).
 constexpr size_t kMaxStreamWorkspaces = 32;
-Workspace* ws_for_stream(hr_index* h, void* stream, std::unique_lock<std::mutex>& held) {
-    std::lock_guard<std::mutex> g(h->pool_mu);
-    auto it = h->stream_ws.find(stream);
+struct StreamWs {
+    hr_index* h = nullptr;
     Workspace* w = nullptr;
-    if (it != h->stream_ws.end()) {
-        w = it->second;
-    } else {
-        if (h->stream_ws.size() >= kMaxStreamWorkspaces) {
-            for (auto jt = h->stream_ws.begin(); jt != h->stream_ws.end();) {
-                Workspace* old = jt->second;
-                if (old->mu.try_lock()) {  // nobody is enqueueing with it, and nobody can get it while pool_mu is held
-                    old->release();        // hipFree waits for the work that still uses the buffers
-                    old->mu.unlock();
-                    delete old;
-                    jt = h->stream_ws.erase(jt);
-                } else {
-                    ++jt;
+    std::unique_lock<std::mutex> held;
+    StreamWs() = default;
+    StreamWs(const StreamWs&) = delete;
+    StreamWs& operator=(const StreamWs&) = delete;
+    ~StreamWs() {
+        if (!w) return;
+        if (held.owns_lock()) held.unlock();
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        --w->users;
+    }
+};
+Workspace* ws_for_stream(hr_index* h, void* stream, StreamWs& out) {
+    std::vector<Workspace*> pruned;
+    Workspace* w = nullptr;
+    {
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        auto it = h->stream_ws.find(stream);
+        if (it != h->stream_ws.end()) {
+            w = it->second;
+        } else {
+            if (h->stream_ws.size() >= kMaxStreamWorkspaces) {
+                for (auto jt = h->stream_ws.begin(); jt != h->stream_ws.end();) {
+                    if (jt->second->users == 0) {  // nobody holds or waits for it, and nobody can get it while pool_mu is held
+                        pruned.push_back(jt->second);
+                        jt = h->stream_ws.erase(jt);
+                    } else {
+                        ++jt;
+                    }
                 }
             }
+            w = new (std::nothrow) Workspace();
+            if (w) h->stream_ws[stream] = w;
         }
-        w = new (std::nothrow) Workspace();
-        if (w) h->stream_ws[stream] = w;
+        if (w) ++w->users;
     }
-    if (w) held = std::unique_lock<std::mutex>(w->mu);
+    for (Workspace* old : pruned) {
+        old->release();  // hipFree waits for the work that still uses the buffers
+        delete old;
+    }
+    if (!w) return nullptr;
+    out.h = h;
+    out.w = w;
+    out.held = std::unique_lock<std::mutex>(w->mu);
     return w;
 }
 
@@ -286,6 +317,9 @@ struct Span {
     }
 };
 
+// Compute units the scans may occupy: their persistent grids are sized to it (hr_set_scan_cus for a masked stream).
+inline int scan_cus(const hr_index* h) { return h->scan_cus > 0 ? std::min(h->scan_cus, h->cu_count) : h->cu_count; }
+
 // Rows (docs) per candidate group.  Small shards (a rank of a multi-GPU corpus) use 16-row
 // groups: 4x less refine traffic per query, and the 4x larger table of group maxima is
 // still small.  Big shards use 64-row groups, where selecting among 4x more maxima would
@@ -316,7 +350,7 @@ hipError_t launch_scan(const hr_index* h, hipStream_t s, const chunk_t* qfrag, c
     }
     const int64_t waves_per_block = threads / 64;
     int64_t blocks = std::min<int64_t>((n_groups + waves_per_block - 1) / waves_per_block,
-                                       (int64_t)h->cu_count * per_cu);
+                                       (int64_t)scan_cus(h) * per_cu);
     blocks = std::max<int64_t>(blocks, 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, s, h->tiles.as<chunk_t>(), qfrag,
                        h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_groups);
@@ -351,7 +385,7 @@ hipError_t launch_scan_bigq(const hr_index* h, hipStream_t s, const chunk_t* qfr
     const size_t lds = (size_t)2 * GQ * 2 * 1024;  // 2 buffers x GQ groups x BKT(2) fragments of 1 KiB
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    int64_t blocks = std::min<int64_t>((n_super + 7) / 8, (int64_t)h->cu_count);
+    int64_t blocks = std::min<int64_t>((n_super + 7) / 8, (int64_t)scan_cus(h));
     blocks = std::max<int64_t>(blocks, 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, h->tiles.as<chunk_t>(), qfrag,
                        h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
@@ -366,14 +400,19 @@ hipError_t launch_scan_bigq_g(const hr_index* h, hipStream_t s, const chunk_t* q
 
 // 256-query pass with the queries in registers and the corpus streamed through LDS (dense_scan_qreg_kernel):
 // fp16 shards whose rows are 24 tiles long (D = 768 after padding; 2 x 24 x 4 fragment registers per wave).
+// hr_debug_option(HR_DEBUG_DENSE_KERNELS) bit mask (tests drive every scan kernel at every shape): 1 = no register-
+// resident 256-query pass, 2 = no tiled-contraction pass, 4 = no k-chunked large-batch pass, 8 = prefer the tiled
+// contraction to the register-resident pass where both apply
+int g_dense_kernels = 0;
+int g_sparse_rpb = 0;     // HR_DEBUG_SPARSE_RPB: doc ranges per sparse-scan block (0 = by shard size)
+int g_group_rows = 0;     // HR_DEBUG_GROUP_ROWS: candidate-group size of handles created from now on (0 = by shard size)
 bool qreg_supported(const hr_index* h) {
-    static const bool off = std::getenv("HBMRAG_NO_QREG") != nullptr;
-    return !off && h->dtype == HR_F16 && h->KT == 24;
+    return !(g_dense_kernels & 1) && h->dtype == HR_F16 && h->KT == 24;
 }
 template <int KT, int NRB, int GW, int NW>
 hipError_t launch_scan_qreg(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
                             int nq, int64_t n_super) {
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(n_super, (int64_t)h->cu_count * (8 / NW)));
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(n_super, (int64_t)scan_cus(h) * (8 / NW)));
     hipLaunchKernelGGL((dense_scan_qreg_kernel<KT, NRB, GW, NW>), dim3((unsigned)blocks), dim3(64 * NW), 0, s,
                        h->tiles.as<chunk_t>(), qfrag, h->scale.as<float>(), mask, gmax, nq, h->n_rows, n_super);
     return hipGetLastError();
@@ -385,17 +424,15 @@ hipError_t launch_scan_qreg_g(const hr_index* h, hipStream_t s, const chunk_t* q
                                               : launch_scan_qreg<24, 4, 2, 8>(h, s, qfrag, mask, gmax, nq, n_super);
 }
 // 256-query pass as a tiled contraction (dense_scan_gemm_kernel): fp16 shards of any row length from 8 tiles up;
-// serves the shapes the register-resident form cannot (D = 1024: BASELINE config 5).  HBMRAG_GEMM=1 prefers it
-// to the qreg form at D = 768 too (A/B).
+// serves the shapes the register-resident form cannot (D = 1024: BASELINE config 5).
 bool gemm_supported(const hr_index* h) {
-    static const bool off = std::getenv("HBMRAG_NO_GEMM") != nullptr;
-    return !off && h->dtype == HR_F16 && h->KT >= 8;
+    return !(g_dense_kernels & 2) && h->dtype == HR_F16 && h->KT >= 8;
 }
 template <int GQ>
 hipError_t launch_scan_gemm_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
                               int nq, int64_t n_super) {
     const int64_t n_tiles = (n_super * kRowBlocksPerSuper + kGemmRowBlocks - 1) / kGemmRowBlocks;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_tiles, h->cu_count));
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_tiles, scan_cus(h)));
     if (group_rows_for(h, h->n_rows) == 16)
         hipLaunchKernelGGL((dense_scan_gemm_kernel<GQ, 1>), dim3(blocks), dim3(512), 0, s, h->tiles.as<chunk_t>(), qfrag,
                            h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
@@ -519,11 +556,10 @@ TopkArgs dense_topk_args(const hr_index* h, Workspace* ws, int C, int GR, int k,
 }
 int launch_refine_sparse(hr_index* h, Workspace* ws, hipStream_t s, const int64_t* d_qptr, const int32_t* d_qidx,
                          const float* d_qval, int B, int C, int GR, int stride, const uint8_t* d_mask) {
-    // docs per wave (HBMRAG_REFINE_DPW, 1..64): shorter chains finish this kernel sooner (0.60 -> 0.55 ms at 10M docs,
-    // 0.168 -> 0.136 ms at 1.25M with 16) but the step does not gain (3.77 -> 3.87 ms; 0.629 -> 0.619 ms): the kernel
-    // runs beside the scans, and what it takes from the HBM sooner they get later.  64 stays.
-    static const int forced_dpw = [] { const char* e = std::getenv("HBMRAG_REFINE_DPW"); return e ? std::atoi(e) : 0; }();
-    const int dpw = (forced_dpw >= 1 && forced_dpw <= 64) ? forced_dpw : 64;
+    // 64 docs per wave: shorter chains finish this kernel sooner (0.60 -> 0.55 ms at 10M docs, 0.168 -> 0.136 ms at 1.25M
+    // with 16) but the step does not gain — the kernel runs beside the scans, and what it takes from the HBM sooner they
+    // get later (round 2 A/B).
+    const int dpw = 64;
     hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 4 * dpw - 1) / (4 * dpw), B), dim3(256),
                        (size_t)kFilterBits / 8 + (size_t)stride * 8, s, h->s_indptr.as<int64_t>(),
                        h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
@@ -556,9 +592,83 @@ TopkArgs sparse_topk_args(const hr_index* h, Workspace* ws, int C, int GR, int k
 }
 
 // Enqueue a complete dense search on stream s.  All pointers are device pointers.
-enum { PHASE_SCAN = 1, PHASE_FINISH = 2, PHASE_ALL = 3 };
+enum { PHASE_SCAN = 1, PHASE_FINISH = 2, PHASE_PREP = 4, PHASE_ALL = 7 };
 
-// Enqueue a dense search on stream s: PHASE_SCAN = query prep + the shard scan (leaves the group
+// ---- the finishing chain as one launch (finish.h) --------------------------------------------------------------
+// One block per (query, modality): worth it when the batch fills a good part of the chip that way and the candidate
+// set fits LDS; otherwise the multi-launch chain, whose refine kernels spread ONE query over many compute units
+// (single-query latency path, escalated searches with hundreds of candidate groups).
+int g_finish_mode = 0;  // hr_debug_option(HR_DEBUG_FINISH_MODE): 0 = by batch size, 1 = always the chain, 2 = fused whenever it fits
+bool finish_fused_ok(int B, int n_mod, int C, int GR, int64_t n_groups) {
+    const int64_t n_buckets = (n_groups + kBucketGroups - 1) / kBucketGroups;
+    if (g_finish_mode == 1) return false;
+    return ((int64_t)B * n_mod >= 64 || g_finish_mode == 2) && C <= kFinishMaxCand && (int64_t)C * GR <= kFinishMaxSlots &&
+           n_buckets <= kFinishMaxBuckets;
+}
+int launch_finish(hr_index* h, hipStream_t s, int B, FinishPair& p) {
+    p.key_slots = 0;
+    for (int i = 0; i < p.n; ++i) p.key_slots = std::max(p.key_slots, p.m[i].sel.C * p.m[i].group_rows);
+    const size_t lds = finish_lds_bytes(p);
+    static bool attr_set = false;  // benign race: the attribute is idempotent
+    if (!attr_set) {
+        HIP_TRY(h, hipFuncSetAttribute((const void*)finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(finish_kernel, dim3(B, p.n), dim3(kFinishThreads), lds, s, p);
+    HIP_TRY(h, hipGetLastError());
+    return HR_OK;
+}
+
+FinishMod finish_mod_dense(hr_index* h, Workspace* ws, const float* d_q, int B, int C, int GR, int64_t n_groups, int k,
+                           const uint8_t* d_mask, int64_t* d_ids, float* d_scores, int32_t* d_flags) {
+    FinishMod m{};
+    m.kind = 0;
+    m.group_rows = GR;
+    m.sel.gmax = ws->gmax.as<float>();
+    m.sel.n_groups = n_groups;
+    m.sel.n_buckets = (n_groups + kBucketGroups - 1) / kBucketGroups;
+    m.sel.C = C;
+    m.sel.two_level = n_groups > C && m.sel.n_buckets > C;
+    m.sel.a_cut = ws->acut.as<float>();
+    m.topk = dense_topk_args(h, ws, C, GR, k, d_ids, d_scores, d_flags);
+    m.rowmask = d_mask;
+    m.tiles = h->tiles.as<chunk_t>();
+    m.KT = h->KT;
+    m.dim = (int)h->dim;
+    m.cosine = h->metric == HR_METRIC_COSINE;
+    m.dtype = h->dtype;
+    m.q = d_q;
+    m.qn2 = ws->qn2.as<double>();
+    m.norm2 = h->norm2.as<double>();
+    m.n_rows = h->n_rows;
+    return m;
+}
+FinishMod finish_mod_sparse(hr_index* h, Workspace* ws, const int64_t* d_qptr, const int32_t* d_qidx, const float* d_qval,
+                            int B, int C, int GR, int64_t n_groups, int stride, int k, const uint8_t* d_mask,
+                            int64_t* d_ids, float* d_scores, int32_t* d_flags) {
+    FinishMod m{};
+    m.kind = 1;
+    m.group_rows = GR;
+    m.sel.gmax = ws->gmax.as<float>();
+    m.sel.n_groups = n_groups;
+    m.sel.n_buckets = (n_groups + kBucketGroups - 1) / kBucketGroups;
+    m.sel.C = C;
+    m.sel.two_level = n_groups > C && m.sel.n_buckets > C;
+    m.sel.a_cut = ws->acut.as<float>();
+    m.topk = sparse_topk_args(h, ws, C, GR, k, d_ids, d_scores, d_flags);
+    m.rowmask = d_mask;
+    m.indptr = h->s_indptr.as<int64_t>();
+    m.idx = h->s_idx.as<int32_t>();
+    m.val = h->s_val.as<float>();
+    m.q_indptr = d_qptr;
+    m.q_idx = d_qidx;
+    m.q_val = d_qval;
+    m.q_cap = stride;
+    m.n_rows = h->n_sparse;
+    return m;
+}
+
+// Enqueue a dense search on stream s: PHASE_PREP = query prep, PHASE_SCAN = the shard scan (leaves the group
 // maxima in ws), PHASE_FINISH = candidate select + refine + top-k from those maxima.
 int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float* d_q, int B, int k,
                          const uint8_t* d_mask, int64_t* d_ids, float* d_scores, int32_t* d_flags, int C,
@@ -568,16 +678,15 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     const int64_t n_groups = n_super * (kSuperRows / GR);  // group maxima per query (tail groups hold -inf)
     const int Gsmall = max_groups_for_dim(h);
     // batches beyond what fits LDS whole go through the k-chunked large-batch pass, 128 or 256 queries at a time
-    static const bool no_bigq = std::getenv("HBMRAG_NO_BIGQ") != nullptr;
-    const bool big = B > 16 * Gsmall && h->KT % 4 == 0 && !no_bigq;
-    static const bool prefer_gemm = std::getenv("HBMRAG_GEMM") != nullptr;
-    static const bool gemm128 = std::getenv("HBMRAG_GEMM128") != nullptr;   // 65..128 queries through the tiled-contraction form
+    const bool big = B > 16 * Gsmall && h->KT % 4 == 0 && !(g_dense_kernels & 4);
+    const bool prefer_gemm = (g_dense_kernels & 8) != 0;
     const bool use_qreg = qreg_supported(h) && !(prefer_gemm && gemm_supported(h));
     const bool big256 = big && B > 128 && (use_qreg || gemm_supported(h));   // 256 queries per pass
     const int Gmax = big256 ? 16 : big ? 8 : Gsmall;
     const int chunk_q = 16 * Gmax;
-    const size_t qfrag_bytes = (size_t)Gmax * h->KT * 1024;
-    HIP_TRY(h, ws->qfrag.ensure(qfrag_bytes));
+    const int n_chunks = (B + chunk_q - 1) / chunk_q;
+    const size_t chunk_frag = (size_t)Gmax * h->KT * kTileChunks;   // 16-byte chunks of one pass's query fragments
+    HIP_TRY(h, ws->qfrag.ensure((size_t)n_chunks * chunk_frag * sizeof(chunk_t)));
     HIP_TRY(h, ws->qn2.ensure((size_t)B * sizeof(double)));
     HIP_TRY(h, ws->gmax.ensure((size_t)B * n_groups * sizeof(float)));
     HIP_TRY(h, ws->cand.ensure((size_t)B * C * sizeof(int32_t)));
@@ -585,44 +694,49 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     HIP_TRY(h, ws->cscore.ensure((size_t)B * C * GR * sizeof(float)));
     HIP_TRY(h, ws->crow.ensure((size_t)B * C * GR * sizeof(int32_t)));
 
+    auto groups_of = [&](int nq) { return big ? ((big256 && nq > 128) ? 16 : 8) : (nq + 15) / 16; };
+    if (phases & PHASE_PREP) {
+        // every pass's queries in one launch: pass c owns fragment groups [c * Gmax, ...) of qfrag (slot = query number)
+        Span sp(h, s, PH_PREP);
+        const int G_total = (n_chunks - 1) * Gmax + groups_of(B - (n_chunks - 1) * chunk_q);
+        if (h->dtype == HR_F16)
+            hipLaunchKernelGGL((prep_queries_kernel<_Float16>), dim3(16 * G_total), dim3(256), 0, s, d_q, B, (int)h->dim,
+                               h->KT, ws->qfrag.as<chunk_t>(), ws->qn2.as<double>());
+        else
+            hipLaunchKernelGGL((prep_queries_kernel<float>), dim3(16 * G_total), dim3(256), 0, s, d_q, B, (int)h->dim,
+                               h->KT, ws->qfrag.as<chunk_t>(), ws->qn2.as<double>());
+        HIP_TRY(h, hipGetLastError());
+    }
     for (int c0 = 0; (phases & PHASE_SCAN) && c0 < B; c0 += chunk_q) {
         const int nq = std::min(chunk_q, B - c0);
         const bool pass256 = big256 && nq > 128;   // a trailing chunk of <= 128 queries takes the 128-query pass
-        const int G = big ? (pass256 ? 16 : 8) : (nq + 15) / 16;
-        {
-            Span sp(h, s, PH_PREP);
-            if (h->dtype == HR_F16)
-                hipLaunchKernelGGL((prep_queries_kernel<_Float16>), dim3(16 * G), dim3(256), 0, s,
-                                   d_q + (int64_t)c0 * h->dim, nq, (int)h->dim, h->KT, ws->qfrag.as<chunk_t>(),
-                                   ws->qn2.as<double>() + c0);
-            else
-                hipLaunchKernelGGL((prep_queries_kernel<float>), dim3(16 * G), dim3(256), 0, s,
-                                   d_q + (int64_t)c0 * h->dim, nq, (int)h->dim, h->KT, ws->qfrag.as<chunk_t>(),
-                                   ws->qn2.as<double>() + c0);
-            HIP_TRY(h, hipGetLastError());
-        }
+        const int G = groups_of(nq);
+        const chunk_t* qf = ws->qfrag.as<chunk_t>() + (size_t)(c0 / chunk_q) * chunk_frag;
         {
             Span sp(h, s, PH_SCAN);
             float* gm = ws->gmax.as<float>() + (int64_t)c0 * n_groups;
             hipError_t e;
             if (pass256)
-                e = use_qreg ? launch_scan_qreg_g(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
-                             : launch_scan_gemm_g<16>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
-            else if (big && gemm128 && gemm_supported(h))
-                e = launch_scan_gemm_g<8>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+                e = use_qreg ? launch_scan_qreg_g(h, s, qf, d_mask, gm, nq, n_super)
+                             : launch_scan_gemm_g<16>(h, s, qf, d_mask, gm, nq, n_super);
             else if (big)
-                e = (h->dtype == HR_F16)
-                        ? launch_scan_bigq_g<_Float16>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
-                        : launch_scan_bigq_g<float>(h, s, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+                e = (h->dtype == HR_F16) ? launch_scan_bigq_g<_Float16>(h, s, qf, d_mask, gm, nq, n_super)
+                                         : launch_scan_bigq_g<float>(h, s, qf, d_mask, gm, nq, n_super);
             else
-                e = (h->dtype == HR_F16)
-                        ? launch_scan_g<_Float16>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super)
-                        : launch_scan_g<float>(h, s, G, ws->qfrag.as<chunk_t>(), d_mask, gm, nq, n_super);
+                e = (h->dtype == HR_F16) ? launch_scan_g<_Float16>(h, s, G, qf, d_mask, gm, nq, n_super)
+                                         : launch_scan_g<float>(h, s, G, qf, d_mask, gm, nq, n_super);
             HIP_TRY(h, e);
         }
     }
     if (scan_done) HIP_TRY(h, hipEventRecord(scan_done, s));
     if (!(phases & PHASE_FINISH)) return HR_OK;
+    if (finish_fused_ok(B, 1, C, GR, n_groups)) {
+        Span sp(h, s, PH_FINISH);
+        FinishPair p{};
+        p.n = 1;
+        p.m[0] = finish_mod_dense(h, ws, d_q, B, C, GR, n_groups, k, d_mask, d_ids, d_scores, d_flags);
+        return launch_finish(h, s, B, p);
+    }
     {
         Span sp(h, s, PH_GSEL);
         HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
@@ -644,9 +758,9 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
 // Doc ranges one scan block walks (sparse_scan_kernel pipelines over them): as many as leave the chip
 // about six rounds of blocks (two blocks per CU), at most 16; gridDim.y must stay below 65536.
 int sparse_ranges_per_block(const hr_index* h, int B) {
-    static const int forced = [] { const char* e = std::getenv("HBMRAG_SPARSE_RPB"); return e ? std::atoi(e) : 0; }();
+    const int forced = g_sparse_rpb;
     const int64_t pairs = (int64_t)B * h->n_ranges;
-    int64_t rpb = forced > 0 ? forced : std::min<int64_t>(16, pairs / (6 * 2 * (int64_t)h->cu_count));
+    int64_t rpb = forced > 0 ? forced : std::min<int64_t>(16, pairs / (6 * 2 * (int64_t)scan_cus(h)));
     rpb = std::max<int64_t>(rpb, (h->n_ranges + 65534) / 65535);
     return (int)std::max<int64_t>(1, rpb);
 }
@@ -665,7 +779,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     HIP_TRY(h, ws->qeps.ensure((size_t)B * sizeof(float)));
     const int64_t V1 = h->sparse_dim + 1;
     const int stride = (int)round_up(std::max(max_q_nnz, 1), 64);  // fixed-stride query layout for the scan
-    if (phases & PHASE_SCAN) {
+    if (phases & PHASE_PREP) {
         HIP_TRY(h, ws->pq_n.ensure((size_t)B * 4));
         HIP_TRY(h, ws->pq_idx.ensure((size_t)B * stride * 4));
         HIP_TRY(h, ws->pq_w.ensure((size_t)B * stride * 4));
@@ -686,6 +800,13 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         HIP_TRY(h, hipGetLastError());
     }
     if (!(phases & PHASE_FINISH)) return HR_OK;
+    if (finish_fused_ok(B, 1, C, GR, n_groups)) {
+        Span sp(h, s, PH_FINISH);
+        FinishPair p{};
+        p.n = 1;
+        p.m[0] = finish_mod_sparse(h, ws, d_qptr, d_qidx, d_qval, B, C, GR, n_groups, stride, k, d_mask, d_ids, d_scores, d_flags);
+        return launch_finish(h, s, B, p);
+    }
     {
         Span sp(h, s, PH_SGSEL);
         HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
@@ -715,6 +836,15 @@ int hybrid_finish_enqueue(hr_index* h, Workspace* wd, Workspace* wsp, hipStream_
     const int64_t n_super = (h->n_rows + kSuperRows - 1) / kSuperRows;
     const int64_t ng_d = n_super * (kSuperRows / GRd), ng_s = (h->n_sparse + GRs - 1) / GRs;
     const int stride = (int)round_up(std::max(max_q_nnz, 1), 64);
+    if (finish_fused_ok(B, 2, C, GRd, ng_d) && finish_fused_ok(B, 2, C, GRs, ng_s)) {
+        for (Workspace* ws : {wd, wsp}) HIP_TRY(h, ws->acut.ensure((size_t)B * sizeof(float)));
+        Span sp(h, s, PH_FINISH);
+        FinishPair p{};
+        p.n = 2;
+        p.m[0] = finish_mod_dense(h, wd, d_q, B, C, GRd, ng_d, k, d_mask, d_ids, d_scores, d_flags);
+        p.m[1] = finish_mod_sparse(h, wsp, d_qptr, d_qidx, d_qval, B, C, GRs, ng_s, stride, k, d_mask, s_ids, s_scores, s_flags);
+        return launch_finish(h, s, B, p);
+    }
     for (Workspace* ws : {wd, wsp}) {
         const int GR = ws == wd ? GRd : GRs;
         HIP_TRY(h, ws->cand.ensure((size_t)B * C * sizeof(int32_t)));
@@ -878,27 +1008,48 @@ int validate_csr(const hr_index* h, const int64_t* indptr, const int32_t* indice
 // keeps no copy of the corpus (reference indexing.py:377-431: insert + flush per index_chunks call).
 int build_sparse(hr_index* h) {
     hipStream_t s = h->ingest_stream;
-    const int64_t n = h->n_sparse, n0 = h->n_sparse_built;
+    const int64_t n = h->n_sparse;
     const int64_t V1 = h->sparse_dim + 1;
-    if (n == n0) return HR_OK;
-    const int64_t new_nnz = (int64_t)h->pend_idx.size();
-    const int64_t nnz = h->nnz_built + new_nnz;
-    // 1. append the staged rows to the device CSR
-    HIP_TRY(h, h->s_indptr.grow((size_t)(n + 1) * 8, (size_t)(n0 + 1) * 8, s));
-    HIP_TRY(h, h->s_idx.grow((size_t)std::max<int64_t>(nnz, 1) * 4, (size_t)h->nnz_built * 4, s));
-    HIP_TRY(h, h->s_val.grow((size_t)std::max<int64_t>(nnz, 1) * 4, (size_t)h->nnz_built * 4, s));
-    for (int64_t& v : h->pend_indptr) v += h->nnz_built;  // absolute entry numbers
-    HIP_TRY(h, hipMemcpyAsync(h->s_indptr.as<int64_t>() + n0, h->pend_indptr.data(), (size_t)(n - n0 + 1) * 8,
-                              hipMemcpyHostToDevice, s));
-    if (new_nnz) {
-        HIP_TRY(h, hipMemcpyAsync(h->s_idx.as<int32_t>() + h->nnz_built, h->pend_idx.data(), (size_t)new_nnz * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(h, hipMemcpyAsync(h->s_val.as<float>() + h->nnz_built, h->pend_val.data(), (size_t)new_nnz * 4, hipMemcpyHostToDevice, s));
+    if (h->n_csr == n && h->n_sparse_built == n) return HR_OK;
+    // 1. append the staged rows to the device CSR.  Restartable: the staging vectors are only read here (the absolute
+    //    row pointers are built in a temporary), and the CSR watermark (n_csr, nnz_csr) is committed together with the
+    //    release of the staging vectors — a failure before that leaves everything as it was, a failure after it
+    //    (step 2) is retried from the device CSR alone.
+    if (h->n_csr < n) {
+        const int64_t n0 = h->n_csr, nnz0 = h->nnz_csr;
+        const int64_t new_nnz = (int64_t)h->pend_idx.size();
+        const int64_t nnz = nnz0 + new_nnz;
+        if ((int64_t)h->pend_indptr.size() != n - n0 + 1) return fail(h, HR_ESTATE, "sparse staging out of step with the row count");
+        std::vector<int64_t> abs_ptr;
+        try {
+            abs_ptr.resize(h->pend_indptr.size());
+        } catch (const std::exception&) {
+            return fail(h, HR_ENOMEM, "out of host memory building sparse row pointers");
+        }
+        for (size_t i = 0; i < abs_ptr.size(); ++i) abs_ptr[i] = h->pend_indptr[i] + nnz0;  // absolute entry numbers
+        HIP_TRY(h, h->s_indptr.grow((size_t)(n + 1) * 8, (size_t)(n0 + 1) * 8, s));
+        HIP_TRY(h, h->s_idx.grow((size_t)std::max<int64_t>(nnz, 1) * 4, (size_t)nnz0 * 4, s));
+        HIP_TRY(h, h->s_val.grow((size_t)std::max<int64_t>(nnz, 1) * 4, (size_t)nnz0 * 4, s));
+        HIP_TRY(h, hipMemcpyAsync(h->s_indptr.as<int64_t>() + n0, abs_ptr.data(), (size_t)(n - n0 + 1) * 8,
+                                  hipMemcpyHostToDevice, s));
+        if (new_nnz) {
+            HIP_TRY(h, hipMemcpyAsync(h->s_idx.as<int32_t>() + nnz0, h->pend_idx.data(), (size_t)new_nnz * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(h, hipMemcpyAsync(h->s_val.as<float>() + nnz0, h->pend_val.data(), (size_t)new_nnz * 4, hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(h, hipStreamSynchronize(s));  // the staging vectors are released below
+        std::vector<int64_t>{0}.swap(h->pend_indptr);
+        std::vector<int32_t>().swap(h->pend_idx);
+        std::vector<float>().swap(h->pend_val);
+        h->n_csr = n;
+        h->nnz_csr = nnz;
     }
-    HIP_TRY(h, hipStreamSynchronize(s));  // the staging vectors are released below
-    std::vector<int64_t>{0}.swap(h->pend_indptr);
-    std::vector<int32_t>().swap(h->pend_idx);
-    std::vector<float>().swap(h->pend_val);
-    // 2. rebuild the posting blocks of ranges r_d .. n_ranges-1
+    if (h->fault_inject == 1) {  // test hook: what an allocation failure in step 2 leaves behind
+        h->fault_inject = 0;
+        return fail(h, HR_ENOMEM, "injected failure after the CSR upload (hr_debug_inject_fault)");
+    }
+    // 2. rebuild the posting blocks of ranges r_d .. n_ranges-1 from the device CSR.  Nothing is committed before the
+    //    last kernel has finished: a retry starts again from the same r_d (h_range_base[0 .. r_d] is never rewritten).
+    const int64_t n0 = h->n_sparse_built;
     const int64_t r_d = n0 / kRangeDocs;          // range of the first new doc
     const int64_t doc0 = r_d * kRangeDocs;
     const int64_t n_ranges = (n + kRangeDocs - 1) / kRangeDocs;
@@ -942,7 +1093,6 @@ int build_sparse(hr_index* h) {
     HIP_TRY(h, hipStreamSynchronize(s));
     h->n_ranges = n_ranges;
     h->n_sparse_built = n;
-    h->nnz_built = nnz;
     return HR_OK;
 }
 
@@ -988,10 +1138,7 @@ int hr_create(int device, int64_t dim, int dtype, int metric, int64_t sparse_dim
         const int tile_elems = 4 * elems_per_chunk(dtype);
         h->KT = (int)round_up((dim + tile_elems - 1) / tile_elems, 4);  // multiple of the scan's prefetch depth
     }
-    if (const char* gr = std::getenv("HBMRAG_GROUP_ROWS")) {
-        const int v = std::atoi(gr);
-        if (v == 16 || v == 64) h->group_rows_override = v;
-    }
+    h->group_rows_override = g_group_rows;
     DeviceGuard dg(device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->cu_count = prop.multiProcessorCount;
@@ -1118,6 +1265,10 @@ int hr_finalize(hr_index* h) {
     std::unique_lock<std::shared_mutex> lk(h->rw);
     DeviceGuard dg(h->device);
     hipStream_t s = h->ingest_stream;
+    // `*_dev` searches drop their shared lock once their kernels are enqueued: a scan still running on a caller's stream
+    // must not see the run tables and posting blocks of the dirty ranges while they are rebuilt in place
+    if ((h->dim > 0 && h->n_normed < h->n_rows) || (h->sparse_dim > 0 && h->n_sparse_built != h->n_sparse))
+        HIP_TRY(h, hipDeviceSynchronize());
     if (h->dim > 0 && h->n_normed < h->n_rows) {
         const int64_t n = h->n_rows - h->n_normed;
         const unsigned blocks = (unsigned)((n + 255) / 256);
@@ -1137,7 +1288,7 @@ int hr_finalize(hr_index* h) {
         std::memcpy(&h->max_row_norm, &bits, 4);
         h->n_normed = h->n_rows;
     }
-    if (h->sparse_dim > 0 && h->n_sparse_built != h->n_sparse) HR_TRY(build_sparse(h));
+    if (h->sparse_dim > 0 && (h->n_sparse_built != h->n_sparse || h->n_csr != h->n_sparse)) HR_TRY(build_sparse(h));
     h->finalized = true;
     return HR_OK;
 }
@@ -1183,7 +1334,7 @@ int save_to(hr_index* h, FILE* f) {
     hd.version = 2; hd.dtype = h->dtype; hd.metric = h->metric; hd.KT = h->KT;
     hd.dim = h->dim; hd.sparse_dim = h->sparse_dim; hd.n_rows = h->n_rows;
     hd.cap_rows = h->dim ? round_up(std::max<int64_t>(h->n_rows, 1), kSuperRows) : 0;
-    hd.n_sparse = h->n_sparse; hd.nnz = h->nnz_built; hd.row_offset = h->row_offset;
+    hd.n_sparse = h->n_sparse; hd.nnz = h->nnz_csr; hd.row_offset = h->row_offset;
     hd.max_row_norm = h->max_row_norm; hd.max_sparse_abs = h->max_sparse_abs;
     const bool dense = h->dim > 0 && h->n_rows > 0;
     hd.file_bytes = (int64_t)sizeof hd + (dense ? (int64_t)tile_bytes_for_rows(h, hd.cap_rows) + hd.cap_rows * 12 : 0) +
@@ -1334,7 +1485,7 @@ int hr_search_dense_dev(hr_index* h, const float* d_q, int B, int k, const uint8
     DeviceGuard dg(h->device);
     hipStream_t s = (hipStream_t)stream;
     if (h->n_rows == 0) return fill_empty(h, s, B, k, d_ids, d_scores, d_flags);
-    std::unique_lock<std::mutex> ws_held;
+    StreamWs ws_held;
     Workspace* ws = ws_for_stream(h, stream, ws_held);
     if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
     return dense_search_enqueue(h, ws, s, d_q, B, k, d_rowmask, d_ids, d_scores, d_flags, candidate_groups_for_k(k));
@@ -1351,7 +1502,7 @@ int hr_search_sparse_dev(hr_index* h, const int64_t* d_q_indptr, const int32_t* 
     DeviceGuard dg(h->device);
     hipStream_t s = (hipStream_t)stream;
     if (h->n_sparse == 0) return fill_empty(h, s, B, k, d_ids, d_scores, d_flags);
-    std::unique_lock<std::mutex> ws_held;
+    StreamWs ws_held;
     Workspace* ws = ws_for_stream(h, stream, ws_held);
     if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
     return sparse_search_enqueue(h, ws, s, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, d_ids, d_scores,
@@ -1372,7 +1523,7 @@ int hr_search_hybrid_dev(hr_index* h, const float* d_q, const int64_t* d_q_indpt
     int64_t* s_ids = d_ids + (size_t)B * k;
     float* s_scores = d_scores + (size_t)B * k;
     int32_t* s_flags = d_flags ? d_flags + B : nullptr;
-    std::unique_lock<std::mutex> ws_held;
+    StreamWs ws_held;
     Workspace* ws = ws_for_stream(h, stream, ws_held);
     if (!ws) return fail(h, HR_ENOMEM, "workspace allocation failed");
     if (!ws->side) {
@@ -1415,9 +1566,10 @@ static int slot_workspaces(hr_index* h, int slot, Workspace** dense, Workspace**
     return HR_OK;
 }
 
-int hr_hybrid_scan_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
-                       const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
-                       const uint8_t* d_rowmask, int slot, void* stream) {
+// phases = PHASE_PREP (hr_hybrid_prep_dev) or the scans (+ the prep when the slot was not prepared beforehand)
+static int hybrid_scan_phases(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                              const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
+                              const uint8_t* d_rowmask, int slot, void* stream, bool prep_only) {
     HR_TRY(check_search_args(h, B, k, true));
     HR_TRY(check_search_args(h, B, k, false));
     if (!d_q || !d_q_indptr || (q_nnz_total > 0 && (!d_q_idx || !d_q_val))) return fail(h, HR_EINVAL, "null buffer");
@@ -1429,12 +1581,29 @@ int hr_hybrid_scan_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr,
     std::lock_guard<std::mutex> slot_held(wd->mu);
     hipStream_t s = (hipStream_t)stream;
     const int C = candidate_groups_for_k(k);
+    int phases = PHASE_PREP;
+    if (!prep_only) {
+        phases = h->slot_prepped[slot] ? PHASE_SCAN : (PHASE_PREP | PHASE_SCAN);
+        h->slot_prepped[slot] = false;
+    }
     if (h->n_rows > 0)
-        HR_TRY(dense_search_enqueue(h, wd, s, d_q, B, k, d_rowmask, nullptr, nullptr, nullptr, C, nullptr, PHASE_SCAN));
+        HR_TRY(dense_search_enqueue(h, wd, s, d_q, B, k, d_rowmask, nullptr, nullptr, nullptr, C, nullptr, phases));
     if (h->n_sparse > 0)
         HR_TRY(sparse_search_enqueue(h, wsp, s, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, nullptr,
-                                     nullptr, nullptr, C, PHASE_SCAN));
+                                     nullptr, nullptr, C, phases));
+    if (prep_only) h->slot_prepped[slot] = true;
     return HR_OK;
+}
+
+int hr_hybrid_prep_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                       const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k, int slot, void* stream) {
+    return hybrid_scan_phases(h, d_q, d_q_indptr, d_q_idx, d_q_val, B, q_nnz_total, max_q_nnz, k, nullptr, slot, stream, true);
+}
+
+int hr_hybrid_scan_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                       const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
+                       const uint8_t* d_rowmask, int slot, void* stream) {
+    return hybrid_scan_phases(h, d_q, d_q_indptr, d_q_idx, d_q_val, B, q_nnz_total, max_q_nnz, k, d_rowmask, slot, stream, false);
 }
 
 int hr_hybrid_finish_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
@@ -1453,8 +1622,7 @@ int hr_hybrid_finish_dev(hr_index* h, const float* d_q, const int64_t* d_q_indpt
     int64_t* s_ids = d_ids + (size_t)B * k;
     float* s_scores = d_scores + (size_t)B * k;
     int32_t* s_flags = d_flags ? d_flags + B : nullptr;
-    static const bool split_chains = std::getenv("HBMRAG_SPLIT_FINISH") != nullptr;  // A/B: the two chains one after the other
-    if (h->n_rows > 0 && h->n_sparse > 0 && !split_chains)
+    if (h->n_rows > 0 && h->n_sparse > 0)
         return hybrid_finish_enqueue(h, wd, wsp, s, d_q, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, d_ids,
                                      d_scores, d_flags, s_ids, s_scores, s_flags, C);
     if (h->n_rows > 0)
@@ -1490,11 +1658,113 @@ int hr_merge_topk_dev(const float* d_scores, const int64_t* d_ids, int n_lists, 
     if (score_stride < (int64_t)B * k_in || id_stride < (int64_t)B * k_in)
         return fail(nullptr, HR_EINVAL, "list stride smaller than one list");
     if (!d_scores || !d_ids || !d_out_ids || !d_out_scores) return fail(nullptr, HR_EINVAL, "null buffer");
-    hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, d_scores, d_ids, n_lists,
-                       score_stride, id_stride, B, k_in, k_out, d_out_ids, d_out_scores);
+    const size_t lds = merge_lds_bytes(n_lists, k_in);
+    if (lds <= kMergeLdsMax)
+        hipLaunchKernelGGL(merge_topk_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, d_scores, d_ids, n_lists,
+                           score_stride, id_stride, k_in, k_out, d_out_ids, d_out_scores);
+    else
+        hipLaunchKernelGGL(merge_topk_big_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, d_scores, d_ids, n_lists,
+                           score_stride, id_stride, k_in, k_out, d_out_ids, d_out_scores);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, HR_EHIP, "merge_topk_kernel: %s", hipGetErrorString(e));
     return HR_OK;
+}
+
+int hr_post_lists_dev(const hr_post_args* a, int B, void* stream) {
+    if (!a || B <= 0) return fail(nullptr, HR_EINVAL, "bad post-lists arguments");
+    if (a->n_lists < 1 || a->top_k <= 0 || a->k_in[0] <= 0) return fail(nullptr, HR_EINVAL, "bad post-lists sizes");
+    size_t lds = 0;
+    for (int m = 0; m < 3; ++m) {
+        if (a->k_in[m] < 0 || a->k_in[m] > HR_MAX_TOPK || a->k_fuse[m] > HR_MAX_TOPK)
+            return fail(nullptr, HR_ELIMIT, "list longer than HR_MAX_TOPK=%d", HR_MAX_TOPK);
+        if (!a->k_in[m]) continue;
+        if (!a->ids[m] || a->k_fuse[m] <= 0) return fail(nullptr, HR_EINVAL, "null list / bad k_fuse of modality %d", m);
+        if (a->n_lists == 1) {
+            if (a->k_fuse[m] != a->k_in[m]) return fail(nullptr, HR_EINVAL, "k_fuse must equal k_in without a merge");
+        } else {
+            if (!a->scores[m] || !a->merged_ids[m] || !a->merged_scores[m])
+                return fail(nullptr, HR_EINVAL, "null merge buffer of modality %d", m);
+            if (a->score_stride < (int64_t)B * a->k_in[m] || a->id_stride < (int64_t)B * a->k_in[m])
+                return fail(nullptr, HR_EINVAL, "list stride smaller than one list");
+            lds = std::max(lds, merge_lds_bytes(a->n_lists, a->k_in[m]));
+        }
+    }
+    if (lds > kMergeLdsMax) return fail(nullptr, HR_ELIMIT, "merge of %d lists does not fit LDS; use hr_merge_topk_dev", a->n_lists);
+    if (!a->fused_ids || !a->fused_scores || !a->fused_methods || !a->fused_n) return fail(nullptr, HR_EINVAL, "null fusion buffer");
+    if (a->rerank && (a->k_out <= 0 || a->top_k > HR_MAX_TOPK || !a->rr_ids || !a->rr_scores || !a->rr_orig))
+        return fail(nullptr, HR_EINVAL, "bad rerank buffers");
+    if (a->agg_flags && a->n_lists > 1 && (!a->flags || a->n_flag_rows <= 0 || a->flag_stride < a->n_flag_rows))
+        return fail(nullptr, HR_EINVAL, "bad flag buffers");
+    PostArgs pa;
+    pa.a = *a;
+    hipLaunchKernelGGL(post_lists_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, pa);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "post_lists_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_stream_create(int device, int priority, const uint32_t* cu_mask, int n_words, void** out_stream) {
+    if (!out_stream || n_words < 0 || (n_words > 0 && !cu_mask)) return fail(nullptr, HR_EINVAL, "bad stream arguments");
+    *out_stream = nullptr;
+    DeviceGuard dg(device);
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (n_words > 0) {
+        // (a masked stream takes the default priority: HIP has no entry point that sets both)
+        e = hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask);
+    } else {
+        int lo = 0, hi = 0;  // lo = numerically greatest = lowest priority
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, std::max(hi, std::min(lo, priority)));
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, HR_EHIP, "stream creation failed: %s", hipGetErrorString(e));
+    }
+    *out_stream = (void*)s;
+    return HR_OK;
+}
+
+int hr_stream_destroy(int device, void* stream) {
+    if (!stream) return HR_OK;
+    DeviceGuard dg(device);
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "hipStreamDestroy: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_set_scan_cus(hr_index* h, int n_cus) {
+    if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+    if (n_cus < 0) return fail(h, HR_EINVAL, "n_cus must be >= 0");
+    h->scan_cus = n_cus;
+    return HR_OK;
+}
+
+int hr_debug_option(hr_index* h, int key, int value) {
+    switch (key) {
+        case HR_DEBUG_FINISH_MODE:
+            if (value < 0 || value > 2) return fail(h, HR_EINVAL, "finish mode must be 0, 1 or 2");
+            g_finish_mode = value;
+            return HR_OK;
+        case HR_DEBUG_DENSE_KERNELS:
+            if (value < 0 || value > 15) return fail(h, HR_EINVAL, "dense kernel mask must be 0..15");
+            g_dense_kernels = value;
+            return HR_OK;
+        case HR_DEBUG_SPARSE_RPB:
+            if (value < 0 || value > 64) return fail(h, HR_EINVAL, "ranges per block must be 0..64");
+            g_sparse_rpb = value;
+            return HR_OK;
+        case HR_DEBUG_GROUP_ROWS:
+            if (value != 0 && value != 16 && value != 64) return fail(h, HR_EINVAL, "group rows must be 0, 16 or 64");
+            g_group_rows = value;
+            return HR_OK;
+        case HR_DEBUG_FAIL_NEXT_BUILD:
+            if (!h) return fail(nullptr, HR_EINVAL, "null handle");
+            h->fault_inject = value ? 1 : 0;
+            return HR_OK;
+        default:
+            return fail(h, HR_EINVAL, "unknown debug option %d", key);
+    }
 }
 
 int hr_rerank_linear_dev(const int64_t* d_ids, const double* d_scores, const int32_t* d_methods, const int32_t* d_n,

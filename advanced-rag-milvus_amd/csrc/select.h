@@ -150,19 +150,14 @@ __global__ __launch_bounds__(256) void bucket_max_kernel(GroupSelPair p) {
 // of every row OUTSIDE the candidate groups (-inf when every group is a
 // candidate).  Groups outside the selected buckets are bounded by the best
 // unselected bucket maximum, groups inside them by the (C+1)-th candidate key.
-__global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelPair p) {
-    __shared__ SelectScratch sh;
-    __shared__ int32_t sel_bucket[HR_MAX_TOPK * 2];  // C <= k + k/2 rounded to 16 (<= 400)
-    const GroupSelArgs& a = p.m[blockIdx.y];
-    const float* __restrict__ gmax = a.gmax;
-    const float* __restrict__ bmax = a.bmax;
+// Block function (any block size that is a multiple of 64): `bm` = the bucket maxima of THIS query (global table row or
+// an LDS copy), `out` = the C candidate slots of this query (global or LDS).
+__device__ inline void select_groups_block(const GroupSelArgs& a, int q, const float* bm, int32_t* out,
+                                           SelectScratch& sh, int32_t* sel_bucket) {
     const int64_t n_groups = a.n_groups, n_buckets = a.n_buckets;
     const int C = a.C;
-    int32_t* __restrict__ cand = a.cand;
     float* __restrict__ a_cut = a.a_cut;
-    const int q = blockIdx.x;
-    const float* gm = gmax + (int64_t)q * n_groups;
-    int32_t* out = cand + (int64_t)q * C;
+    const float* gm = a.gmax + (int64_t)q * n_groups;
     const float NEG_INF = -__builtin_inff();
     if (n_groups <= C) {
         for (int i = threadIdx.x; i < C; i += blockDim.x) out[i] = (i < n_groups) ? i : -1;
@@ -176,7 +171,6 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelPair p) {
         nb = (int)n_buckets;
         for (int i = threadIdx.x; i < nb; i += blockDim.x) sel_bucket[i] = i;
     } else {
-        const float* bm = bmax + (int64_t)q * n_buckets;
         auto bkey = [&](int64_t i) { return rank_key(bm[i], (uint32_t)i); };
         const uint64_t t_b = block_kth_largest(bkey, n_buckets, C + 1, sh);
         bucket_cut = key_score(t_b);
@@ -209,6 +203,14 @@ __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelPair p) {
     }
 }
 
+__global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelPair p) {
+    __shared__ SelectScratch sh;
+    __shared__ int32_t sel_bucket[HR_MAX_TOPK * 2];  // C <= k + k/2 rounded to 16 (<= 400)
+    const GroupSelArgs& a = p.m[blockIdx.y];
+    const int q = blockIdx.x;
+    select_groups_block(a, q, a.bmax + (int64_t)q * a.n_buckets, a.cand + (int64_t)q * a.C, sh, sel_bucket);
+}
+
 // One block per query.  n candidates (score, row; row < 0 = invalid) -> the
 // best K by (score desc, row asc), sorted, as global ids.  flags[q] = 1 when
 // the result is provably the exact top-K of the whole shard:
@@ -237,29 +239,13 @@ struct TopkPair {
     int n;
 };
 
-__global__ __launch_bounds__(1024) void select_topk_kernel(TopkPair p) {
-    __shared__ SelectScratch sh;
-    __shared__ uint64_t sel[HR_MAX_TOPK];
-    const TopkArgs& a = p.m[blockIdx.y];
-    const float* __restrict__ cscore = a.cscore;
-    const int32_t* __restrict__ crow = a.crow;
+// Block function: key(i), i < n = the ranking key of candidate i (0 = invalid) from wherever the refine left it.
+template <typename KeyFn>
+__device__ inline void select_topk_block(const TopkArgs& a, int q, KeyFn key, SelectScratch& sh, uint64_t* sel) {
     const int n = a.n, K = a.K;
     const int64_t row_offset = a.row_offset;
-    const float* __restrict__ a_cut = a.a_cut;
-    const float cut_floor = a.cut_floor, eps_abs = a.eps_abs, eps_rel = a.eps_rel;
-    const float* __restrict__ eps_abs_q = a.eps_abs_q;
-    const int norm_mode = a.norm_mode;
-    const double* __restrict__ qn2 = a.qn2;
     int64_t* __restrict__ out_ids = a.out_ids;
     float* __restrict__ out_scores = a.out_scores;
-    int32_t* __restrict__ flags = a.flags;
-    const int q = blockIdx.x;
-    const float* cs = cscore + (int64_t)q * n;
-    const int32_t* cr = crow + (int64_t)q * n;
-    auto key = [&](int64_t i) -> uint64_t {
-        int32_t r = cr[i];
-        return r < 0 ? 0ull : rank_key(cs[i], (uint32_t)r);
-    };
     const int Ke = K < n ? K : n;
     uint64_t thr = 0;
     if (Ke > 0) thr = block_kth_largest(key, n, Ke, sh);
@@ -286,25 +272,39 @@ __global__ __launch_bounds__(1024) void select_topk_kernel(TopkPair p) {
         out_ids[(int64_t)q * K + i] = -1;
         out_scores[(int64_t)q * K + i] = 0.f;
     }
-    if (flags && threadIdx.x == 0) {
-        const float cut = a_cut[q];
+    if (a.flags && threadIdx.x == 0) {
+        const float cut = a.a_cut[q];
         int exact = 0;
-        if (cut == -__builtin_inff() || cut <= cut_floor) {
+        if (cut == -__builtin_inff() || cut <= a.cut_floor) {
             exact = 1;
         } else if (found == K) {
             uint64_t kth = sel[0];
             for (int j = 1; j < found; ++j) kth = sel[j] < kth ? sel[j] : kth;
             double sk = (double)key_score(kth);
-            if (norm_mode == 1) {
-                double nq = qn2[q];
+            if (a.norm_mode == 1) {
+                double nq = a.qn2[q];
                 sk = nq > 0.0 ? sk / sqrt(nq) : 0.0;
             }
-            double bound = (double)cut + (double)eps_abs + (eps_abs_q ? (double)eps_abs_q[q] : 0.0) +
-                           (double)eps_rel * fabs((double)cut);
+            double bound = (double)cut + (double)a.eps_abs + (a.eps_abs_q ? (double)a.eps_abs_q[q] : 0.0) +
+                           (double)a.eps_rel * fabs((double)cut);
             exact = sk > bound;
         }
-        flags[q] = exact;
+        a.flags[q] = exact;
     }
+}
+
+__global__ __launch_bounds__(1024) void select_topk_kernel(TopkPair p) {
+    __shared__ SelectScratch sh;
+    __shared__ uint64_t sel[HR_MAX_TOPK];
+    const TopkArgs& a = p.m[blockIdx.y];
+    const int q = blockIdx.x;
+    const float* cs = a.cscore + (int64_t)q * a.n;
+    const int32_t* cr = a.crow + (int64_t)q * a.n;
+    auto key = [&](int64_t i) -> uint64_t {
+        int32_t r = cr[i];
+        return r < 0 ? 0ull : rank_key(cs[i], (uint32_t)r);
+    };
+    select_topk_block(a, q, key, sh, sel);
 }
 
 }  // namespace hbmrag

@@ -509,44 +509,43 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
 constexpr int kFilterBits = 32768;
 constexpr int kRefinePrefetch = 2;
 
-__global__ __launch_bounds__(256) void refine_sparse_kernel(
-    const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
-    const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
-    const float* __restrict__ q_val, const uint8_t* __restrict__ rowmask,
-    const int32_t* __restrict__ cand, int C, int group_docs, int64_t n_docs, int q_cap, int docs_per_wave,
-    float* __restrict__ out_score, int32_t* __restrict__ out_row) {
-    // dynamic LDS: filter words, then q_cap query indices and q_cap query values (q_cap = the batch's
-    // longest query rounded up, so short queries leave the CU room for many blocks)
-    extern __shared__ unsigned int refine_lds[];
-    unsigned int* s_filter = refine_lds;
-    int32_t* s_idx = reinterpret_cast<int32_t*>(refine_lds + kFilterBits / 32);
-    float* s_val = reinterpret_cast<float*>(s_idx + q_cap);
-    const int qi = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+// Stage query qi in LDS for the refine: s_filter (kFilterBits / 32 words), s_idx / s_val (q_cap entries each).
+// All threads of the block take part; returns the number of staged terms.
+__device__ inline int refine_sparse_stage_query(const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
+                                                const float* __restrict__ q_val, int qi, int q_cap,
+                                                unsigned int* s_filter, int32_t* s_idx, float* s_val) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
     const int64_t t0 = q_indptr[qi];
     // a query longer than q_cap was already marked "never proven" by the prep kernel (q_eps = inf)
     const int nt = min((int)(q_indptr[qi + 1] - t0), q_cap);
-    for (int i = tid; i < kFilterBits / 32; i += 256) s_filter[i] = 0u;
+    for (int i = tid; i < kFilterBits / 32; i += nthr) s_filter[i] = 0u;
     __syncthreads();
-    for (int i = tid; i < nt; i += 256) {
+    for (int i = tid; i < nt; i += nthr) {
         const int32_t t = q_idx[t0 + i];
         s_idx[i] = t;
         s_val[i] = q_val[t0 + i];
         atomicOr(&s_filter[(t & (kFilterBits - 1)) >> 5], 1u << (t & 31));
     }
     __syncthreads();
-    const int n_slots = C * group_docs;
-    // A wave's docs are a serial chain (each waits for its entries): docs_per_wave (8..64, the host's choice) trades the
-    // length of that chain against the number of blocks that rebuild the filter.
-    const int slot0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (tid >> 6)) * docs_per_wave);  // first doc slot of this wave
-    if (slot0 >= n_slots) return;
-    const int n_here = min(docs_per_wave, n_slots - slot0);
+    return nt;
+}
+
+// One wave walks the n_here (<= 64) candidate doc slots slot0 .. slot0 + n_here - 1 of a query whose terms are staged in
+// LDS; emit(slot, keep, score, doc) is called once per slot by the lane that owns it.
+template <typename Emit>
+__device__ inline void refine_sparse_chain(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                           const float* __restrict__ val, const uint8_t* __restrict__ rowmask,
+                                           const int32_t* cand_q, int group_docs, int64_t n_docs, int slot0, int n_here,
+                                           const unsigned int* s_filter, const int32_t* s_idx, const float* s_val, int nt,
+                                           Emit emit) {
+    const int lane = threadIdx.x & 63;
     // lane l describes doc slot0 + l
     const int slot = slot0 + lane;
     int64_t doc = -1, p0 = 0;
     int len = 0;
     bool valid = false;
     if (lane < n_here) {
-        const int32_t group = cand[(int64_t)qi * C + slot / group_docs];
+        const int32_t group = cand_q[slot / group_docs];
         doc = (int64_t)group * group_docs + slot % group_docs;
         valid = group >= 0 && doc < n_docs;
         if (valid && rowmask) valid = (rowmask[doc >> 3] >> (doc & 7)) & 1;
@@ -632,12 +631,35 @@ __global__ __launch_bounds__(256) void refine_sparse_kernel(
             }
         }
     }
-    if (lane < n_here) {
-        const int64_t o = (int64_t)qi * n_slots + slot;
-        const bool keep = valid && my_score > 0.f;
-        out_score[o] = keep ? my_score : -__builtin_inff();
-        out_row[o] = keep ? (int32_t)doc : -1;
-    }
+    if (lane < n_here) emit(slot, valid && my_score > 0.f, my_score, doc);
+}
+
+__global__ __launch_bounds__(256) void refine_sparse_kernel(
+    const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
+    const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
+    const float* __restrict__ q_val, const uint8_t* __restrict__ rowmask,
+    const int32_t* __restrict__ cand, int C, int group_docs, int64_t n_docs, int q_cap, int docs_per_wave,
+    float* __restrict__ out_score, int32_t* __restrict__ out_row) {
+    // dynamic LDS: filter words, then q_cap query indices and q_cap query values (q_cap = the batch's
+    // longest query rounded up, so short queries leave the CU room for many blocks)
+    extern __shared__ unsigned int refine_lds[];
+    unsigned int* s_filter = refine_lds;
+    int32_t* s_idx = reinterpret_cast<int32_t*>(refine_lds + kFilterBits / 32);
+    float* s_val = reinterpret_cast<float*>(s_idx + q_cap);
+    const int qi = blockIdx.y, tid = threadIdx.x;
+    const int nt = refine_sparse_stage_query(q_indptr, q_idx, q_val, qi, q_cap, s_filter, s_idx, s_val);
+    const int n_slots = C * group_docs;
+    // A wave's docs are a serial chain (each waits for its entries): docs_per_wave (8..64, the host's choice) trades the
+    // length of that chain against the number of blocks that rebuild the filter.
+    const int slot0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (tid >> 6)) * docs_per_wave);  // first doc slot of this wave
+    if (slot0 >= n_slots) return;
+    const int n_here = min(docs_per_wave, n_slots - slot0);
+    refine_sparse_chain(indptr, idx, val, rowmask, cand + (int64_t)qi * C, group_docs, n_docs, slot0, n_here, s_filter,
+                        s_idx, s_val, nt, [&](int slot, bool keep, float score, int64_t doc) {
+                            const int64_t o = (int64_t)qi * n_slots + slot;
+                            out_score[o] = keep ? score : -__builtin_inff();
+                            out_row[o] = keep ? (int32_t)doc : -1;
+                        });
 }
 
 }  // namespace hbmrag

@@ -213,6 +213,16 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3,
                     help="query batches kept in flight: 1 = one batch at a time; 2..4 = scans of batch i+1 on a heavy "
                          "stream while batch i is finished (select/refine/exchange/fuse) on a light stream")
+    ap.add_argument("--simulate-ranks", type=int, default=0,
+                    help="one process, one GPU: put the post-exchange work of a W-rank step (merge of W lists per modality, "
+                         "fed with W copies of the local lists) on the finishing stream — with --rows N/W a PROJECTION of "
+                         "the per-rank step of an N-row corpus on W GPUs; the collective itself is not simulated")
+    ap.add_argument("--light-cus", type=int, default=0,
+                    help="confine the finishing + prep streams to this many compute units and the scans to the rest "
+                         "(CU-masked HIP streams); 0 = no masks, stream priorities only")
+    ap.add_argument("--no-prep-stream", action="store_true", help="query prep on the scan stream (the round-2 arrangement)")
+    ap.add_argument("--finish-mode", choices=("auto", "chain", "fused"), default="auto",
+                    help="finishing path: auto = fused kernel for batches that fill the chip, chain = five launches")
     args = ap.parse_args()
 
     import torch
@@ -306,8 +316,11 @@ def main():
     Q, SQ = make_queries(n_batches, B, D, dist=args.sparse_dist)
     cfg = EngineConfig(top_k=args.top_k, use_sparse=use_sparse)
     n_fly = max(1, args.in_flight) if use_sparse else 1
-    eng = PipelinedSearchEngine(h, cfg, device=str(dev), depth=n_fly) if n_fly > 1 else \
-        HybridSearchEngine(h, cfg, device=str(dev))
+    nat.debug_option(nat.HR_DEBUG_FINISH_MODE, {"auto": 0, "chain": 1, "fused": 2}[args.finish_mode])
+    sim = args.simulate_ranks if world == 1 else 0
+    eng = PipelinedSearchEngine(h, cfg, device=str(dev), depth=n_fly, simulate_ranks=sim, light_cus=args.light_cus,
+                                prep_stream=not args.no_prep_stream) if n_fly > 1 else \
+        HybridSearchEngine(h, cfg, device=str(dev), simulate_ranks=sim)
     dQ = [torch.from_numpy(Q[i]).to(dev) for i in range(n_batches)]
     dS = [eng.upload_sparse(pack_sparse_queries(SQ[i], 0.2)) if use_sparse else None for i in range(n_batches)]
     kp = 2 * args.top_k
@@ -440,6 +453,31 @@ def main():
         dist.all_reduce(ft, op=dist.ReduceOp.MIN)
         flags_exact = bool(ft.item())
 
+    # the finishing kernel and the post-exchange kernel of the last batch once more, ALONE on an idle chip (their
+    # in-region times are those of kernels starved by the scans they run beside): what the chain costs by itself
+    alone = None
+    if n_fly > 1 and use_sparse:
+        torch.cuda.synchronize()
+        st = torch.cuda.current_stream(dev)
+        b, slot = out, (eng._n - 1) % eng.depth
+        q_, (ip_, ix_, iv_, mx_) = dQ[(args.warmup + args.steps - 1) % n_batches], dS[(args.warmup + args.steps - 1) % n_batches]
+        def timed(fn, reps=30):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(reps):
+                fn()
+            e1.record(st)
+            e1.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        fin_us = timed(lambda: h.hybrid_finish_dev(q_.data_ptr(), ip_.data_ptr(), ix_.data_ptr(), iv_.data_ptr(), B, int(mx_), kp,
+                                                   slot, b["ids"].data_ptr(), b["scores"].data_ptr(), b["flags"].data_ptr(),
+                                                   st.cuda_stream))
+        pa = eng._post_args(b, B, eng.n_lists, b.get("gathered"))
+        post_us = timed(lambda: nat.post_lists_dev(pa, B, st.cuda_stream))
+        alone = {"finish_us": fin_us, "post_lists_us": post_us, "lists_merged_per_modality": eng.n_lists,
+                 "note": "back-to-back launches on an idle chip, launch overhead included"}
+
     # every rank merges the same gathered lists, so every rank must hold the same fused answer for the last batch
     ranks_agree = None
     if world > 1:
@@ -532,6 +570,11 @@ def main():
                                                    else "(BASELINE config 5 on one GPU)" if (N, D, B, use_sparse) == (50_000_000, 1024, 256, False) else "")),
                        "rows": N, "dim": D, "batch": B, "top_k": args.top_k, "k_prime": kp,
                        "batches_in_flight": n_fly,
+                       "streams": ("heavy (scans) + light (finish, exchange, post)" + ("" if args.no_prep_stream else " + prep (query preparation)")
+                                   + (f"; CU masks: {args.light_cus} CUs for light + prep, the rest for the scans" if args.light_cus else "; priorities only")) if n_fly > 1 else "one stream",
+                       "finish": args.finish_mode,
+                       **({"simulate_ranks": sim, "projection": f"per-rank step of a {N * sim}-row corpus on {sim} GPUs: the merge of {sim} lists per modality "
+                           "runs on the finishing stream, the all-gather itself is NOT included"} if sim else {}),
                        "parallelism": f"row-sharded x{world}, one RCCL all-gather of per-shard top-k' per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": scan_kernel_name(B, D), "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy": achieved / HBM_COPY_GBPS,
@@ -547,6 +590,7 @@ def main():
             **({"cross_encoder": ce_report(ce, ce_events, ce_pairs, args.ce_seq_len)} if args.rerank == "cross-encoder" else {}),
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
+            **({"finishing_alone": alone} if alone else {}),
             "all_lists_proven_exact": flags_exact, **({"ranks_agree": ranks_agree} if ranks_agree is not None else {}),
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
         }

@@ -187,6 +187,12 @@ HR_API int hr_search_hybrid_dev(hr_index* h, const float* d_q, const int64_t* d_
  * latency-bound tail hides behind them.  The caller orders the phases of one
  * slot with events; `finish` takes the same query buffers as `scan`. */
 #define HR_MAX_SLOTS 4
+/* Optional phase 0: the query preparation of `slot` alone (unit-normalised fragment-order queries, canonical |q|^2,
+ * fixed-stride sparse queries and their fixed-point scale) on a stream of the caller's choice, so that the stream
+ * that carries the scans carries nothing else.  The next hr_hybrid_scan_dev on the same slot then enqueues the two
+ * scans only; the caller orders prep -> scan with an event.  Without this call `scan` prepares the queries itself. */
+HR_API int hr_hybrid_prep_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
+                       const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k, int slot, void* stream);
 HR_API int hr_hybrid_scan_dev(hr_index* h, const float* d_q, const int64_t* d_q_indptr, const int32_t* d_q_idx,
                        const float* d_q_val, int B, int64_t q_nnz_total, int max_q_nnz, int k,
                        const uint8_t* d_rowmask, int slot, void* stream);
@@ -200,11 +206,13 @@ HR_API int hr_fuse_rrf_dev(const int64_t* d_ids_a, int ka, const int64_t* d_ids_
                     int rrf_k, int top_k, int64_t* d_out_ids, double* d_out_scores,
                     int32_t* d_out_methods, int32_t* d_n_out, void* stream);
 /* Cross-shard merge after the RCCL all-gather: n_lists per-shard lists of
- * k_in (score, id) pairs per query; list l starts l*score_stride floats /
- * l*id_stride int64s after the base pointers and is laid out [B][k_in] (so the
- * lists can sit inside the ranks' slots of one all-gather buffer); output the
- * best k_out by (score desc, id asc).  (No reference analogue: Milvus merges
- * its num_shards=4 segments server-side, indexing.py:234-239.) */
+ * k_in (score, id) pairs per query, each sorted by score descending as the
+ * search entry points write them (ids < 0 pad the tail); list l starts
+ * l*score_stride floats / l*id_stride int64s after the base pointers and is
+ * laid out [B][k_in] (so the lists can sit inside the ranks' slots of one
+ * all-gather buffer); output the best k_out by (score desc, id asc).  (No
+ * reference analogue: Milvus merges its num_shards=4 segments server-side,
+ * indexing.py:234-239.) */
 HR_API int hr_merge_topk_dev(const float* d_scores, const int64_t* d_ids, int n_lists, int64_t score_stride,
                       int64_t id_stride, int B, int k_in, int k_out, int64_t* d_out_ids,
                       float* d_out_scores, void* stream);
@@ -219,6 +227,51 @@ HR_API int hr_rerank_linear_dev(const int64_t* d_ids, const double* d_scores, co
                          double method_bonus, double recency_w, int k_out, int64_t* d_out_ids,
                          double* d_out_scores, double* d_out_orig, void* stream);
 
+/* Everything after the per-shard lists of a query batch in ONE launch (one block per query): [hr_merge_topk_dev of
+ * every modality's exchanged lists] -> hr_fuse_rrf_dev -> [hr_rerank_linear_dev]; results are bit-identical to the
+ * separate calls (reference retrieval.py:421-491 fusion, :518-563 rerank, after the server-side shard merge of
+ * indexing.py:234-239).  Modality m = 0 semantic, 1 sparse, 2 domain; k_in[m] = 0 leaves a modality out.
+ *   n_lists = 1: ids[m] are [B][k_in[m]] lists fused as they are (k_fuse[m] must equal k_in[m]; scores/merged_* unused);
+ *   n_lists > 1: ids[m] / scores[m] point at list 0 of modality m inside the gathered buffer, list l lies l*id_stride
+ *                int64s / l*score_stride floats further; the merged [B][k_fuse[m]] lists are written to merged_*[m]
+ *                and fused.
+ * fused_* are [B][top_k] (+ fused_n[B]); with rerank != 0 the learned-ranker outputs rr_* are [B][k_out].
+ * B blocks are launched: agg_flags (if asked for) is filled by strided loops over all n_flag_rows. */
+typedef struct hr_post_args {
+    const int64_t* ids[3];
+    const float* scores[3];
+    int32_t k_in[3];
+    int32_t k_fuse[3];
+    int32_t n_lists;
+    int32_t rrf_k;
+    int64_t id_stride, score_stride;
+    int64_t* merged_ids[3];
+    float* merged_scores[3];
+    double w[3];
+    int64_t* fused_ids;
+    double* fused_scores;
+    int32_t* fused_methods;
+    int32_t* fused_n;
+    int32_t top_k;
+    int32_t rerank;
+    double base_w, method_bonus, recency_w;
+    const double* recency;
+    int32_t k_out;
+    int32_t reserved;
+    int64_t* rr_ids;
+    double* rr_scores;
+    double* rr_orig;
+    /* optional (n_lists > 1): the per-list "proven exact" flags that travelled with the lists — list l's flags are
+     * n_flag_rows int32 ([modality][B]) starting l*flag_stride int32s after `flags`; agg_flags[n_flag_rows] receives
+     * their minimum over the lists (a list is proven iff every shard proved its part) */
+    const int32_t* flags;
+    int64_t flag_stride;
+    int32_t n_flag_rows;
+    int32_t reserved2;
+    int32_t* agg_flags;
+} hr_post_args;
+HR_API int hr_post_lists_dev(const hr_post_args* args, int B, void* stream);
+
 /* ---- encoder / cross-encoder forward: fused elementwise pieces -----------------
  * The GEMMs and the attention of the PyTorch-ROCm encoder forwards stay with
  * hipBLASLt / SDPA; this is the residual add + LayerNorm every post-LN BERT
@@ -230,15 +283,45 @@ HR_API int hr_rerank_linear_dev(const int64_t* d_ids, const double* d_scores, co
 HR_API int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
                              void* d_out, int64_t rows, int hidden, float eps, void* stream);
 
+/* ---- streams with a compute-unit mask -------------------------------------------
+ * A HIP stream whose kernels may only occupy the compute units named by `cu_mask` (bit i of word i/32 = CU i;
+ * n_words 32-bit words; on gfx950 consecutive bits alternate over the 8 XCDs) — the way to keep a latency-bound
+ * finishing chain and the bandwidth-bound scans off each other's compute units.  priority: 0 = default, negative =
+ * higher.  The stream is an ordinary hipStream_t for every other purpose (torch.cuda.ExternalStream wraps it).
+ * hr_set_scan_cus tells the scans how many compute units their stream may use (their persistent grids are sized to
+ * it; 0 = all of the device's). */
+HR_API int hr_stream_create(int device, int priority, const uint32_t* cu_mask, int n_words, void** out_stream);
+HR_API int hr_stream_destroy(int device, void* stream);
+HR_API int hr_set_scan_cus(hr_index* h, int n_cus);
+
+/* ---- test / diagnosis hooks ---------------------------------------------------------
+ * HR_DEBUG_FINISH_MODE (process-wide, handle may be NULL): 0 = choose the finishing path by batch size (default),
+ *   1 = always the multi-launch chain, 2 = the fused finishing kernel whenever the candidate set fits LDS — lets the
+ *   parity tests drive both paths at any batch size.
+ * HR_DEBUG_FAIL_NEXT_BUILD: value != 0 makes the next hr_finalize fail after the sparse rows have reached the device
+ *   CSR and before the postings are rebuilt (what an allocation failure at that point leaves behind); the
+ *   finalize after that must complete the build.
+ * HR_DEBUG_DENSE_KERNELS (process-wide): bit mask that takes dense scan kernels out of the selection so that the
+ *   others serve the shapes they would have served — 1 = no register-resident 256-query pass, 2 = no tiled-contraction
+ *   pass, 4 = no k-chunked large-batch pass, 8 = prefer the tiled contraction where both 256-query passes apply.
+ * HR_DEBUG_SPARSE_RPB (process-wide): doc ranges one sparse-scan block walks (0 = by shard size).
+ * HR_DEBUG_GROUP_ROWS (process-wide): rows per candidate group (16 or 64; 0 = by shard size) of handles created
+ *   afterwards.
+ * The library reads no environment variables. */
+enum { HR_DEBUG_FINISH_MODE = 1, HR_DEBUG_FAIL_NEXT_BUILD = 2, HR_DEBUG_DENSE_KERNELS = 3, HR_DEBUG_SPARSE_RPB = 4,
+       HR_DEBUG_GROUP_ROWS = 5 };
+HR_API int hr_debug_option(hr_index* h, int key, int value);
+
 /* ---- measurement hooks -------------------------------------------------------
  * hr_set_profiling(1) brackets every dense-scan and sparse-scan launch with
- * HIP events on the stream it is launched on; (2) brackets all nine phases:
+ * HIP events on the stream it is launched on; (2) brackets all ten phases:
  * [0] query prep, [1] dense scan, [2] group select, [3] refine, [4] top-k,
- * [5] sparse scan, [6] sparse select, [7] sparse refine, [8] sparse top-k.
+ * [5] sparse scan, [6] sparse select, [7] sparse refine, [8] sparse top-k,
+ * [9] the fused finishing kernel (select + refine + top-k of a batch in one launch).
  * hr_last_kernel_ms drains the recorded spans: out_ms[p] = mean ms per launch
  * of phase p since the previous call, out_ms[HR_N_PHASES + p] = launches
  * averaged.  n must be >= 2*HR_N_PHASES. */
-#define HR_N_PHASES 9
+#define HR_N_PHASES 10
 HR_API int hr_set_profiling(hr_index* h, int enabled);
 HR_API int hr_last_kernel_ms(hr_index* h, float* out_ms, int n);
 /* Algorithmic bytes one dense scan launch reads (rows*dim*sizeof(elem) + 4*rows). */
