@@ -1,0 +1,240 @@
+"""Coalescing of concurrent `MilvusIndexManager.search` calls into batched device searches.
+
+The reference serves up to 64 in-flight `retrieve()` calls on one event loop (service.py:136,149); each of them
+gathers its two or three `index_manager.search` calls (retrieval.py:293-306), and every such call is one RPC that the
+Milvus server is free to batch with the others (indexing.py:503-506 runs it in a worker thread).  Here a search is a
+scan of the whole shard, so the counterpart of the server's request queue is this front: calls that arrive while a
+round of scans is in flight — or within a short window of the first call of a round — are packed per
+(collection, top_k, filter expression, search params) into ONE `hr_search_dense_dev` / `hr_search_sparse_dev` batch
+(and the rank fusions of the same callers into one `hr_fuse_rrf_dev`), run on the front's own stream with one
+synchronisation per round, and the per-query lists are handed back to the awaiting coroutines.  Lists the device form
+could not prove exact are redone through the host form, which widens the candidate set by itself.
+
+One worker thread per manager; the event loop never blocks on the GPU.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+import time
+from concurrent.futures import Future
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .engine import pack_sparse_queries
+
+
+@dataclass
+class _Request:
+    kind: str                 # "dense" | "sparse" | "fuse"
+    key: Tuple                # requests with equal (kind, key) share a launch
+    payload: Any
+    future: Future = field(default_factory=Future)
+
+
+class SearchCoalescer:
+    """Batches requests of one MilvusIndexManager.  `max_batch` bounds the queries per launch (256 = the largest single
+    dense pass); `window_s` is how long a round keeps collecting while requests keep arriving."""
+
+    def __init__(self, manager, max_batch: int = 256, window_s: float = 200e-6):
+        self.mgr = manager
+        self.max_batch = int(max_batch)
+        self.window_s = float(window_s)
+        self._q: "queue.SimpleQueue[Optional[_Request]]" = queue.SimpleQueue()
+        self._thread: Optional[threading.Thread] = None
+        self._lock = threading.Lock()
+        self._closed = False
+        self.stats = {"rounds": 0, "requests": 0, "dense_launches": 0, "sparse_launches": 0, "fuse_launches": 0,
+                      "max_batch_seen": 0, "redone_unproven": 0, "busy_s": 0.0}
+
+    # ------------------------------------------------------------------ front
+    def submit(self, kind: str, key: Tuple, payload: Any) -> Future:
+        req = _Request(kind, key, payload)
+        with self._lock:
+            if self._closed:
+                raise RuntimeError("search front is closed")
+            if self._thread is None:
+                self._thread = threading.Thread(target=self._run, name="search-coalescer", daemon=True)
+                self._thread.start()
+        self._q.put(req)
+        return req.future
+
+    def close(self):
+        with self._lock:
+            self._closed = True
+            t = self._thread
+        if t is not None:
+            self._q.put(None)
+            t.join(timeout=30)
+
+    # ------------------------------------------------------------------ worker
+    def _collect(self) -> Optional[List[_Request]]:
+        first = self._q.get()
+        if first is None:
+            return None
+        reqs = [first]
+        t0 = time.perf_counter()
+        idle_polls = 0
+        while len(reqs) < 4 * self.max_batch:
+            try:
+                r = self._q.get_nowait()
+            except queue.Empty:
+                # nothing queued: give the callers that are being scheduled right now (the sibling searches of the
+                # same retrieve(), the other coroutines of a burst) a moment, but never more than the window
+                if time.perf_counter() - t0 >= self.window_s or idle_polls >= 3:
+                    break
+                idle_polls += 1
+                time.sleep(20e-6)
+                continue
+            if r is None:
+                self._q.put(None)  # close() arrived behind real work: finish this round first
+                break
+            idle_polls = 0
+            reqs.append(r)
+        return reqs
+
+    def _run(self):
+        import torch
+        dev = torch.device("cuda", self.mgr.device)
+        stream = torch.cuda.Stream(dev)
+        while True:
+            reqs = self._collect()
+            if reqs is None:
+                return
+            t0 = time.perf_counter()
+            groups: Dict[Tuple, List[_Request]] = {}
+            for r in reqs:
+                groups.setdefault((r.kind, r.key), []).append(r)
+            self.stats["rounds"] += 1
+            self.stats["requests"] += len(reqs)
+            launched = []
+            with torch.cuda.stream(stream):
+                for (kind, key), rs in groups.items():
+                    for c0 in range(0, len(rs), self.max_batch):
+                        chunk = rs[c0:c0 + self.max_batch]
+                        self.stats["max_batch_seen"] = max(self.stats["max_batch_seen"], len(chunk))
+                        try:
+                            launched.append((kind, key, chunk, getattr(self, "_enqueue_" + kind)(torch, dev, stream, key, chunk)))
+                        except Exception as e:   # a bad batch must not take the other groups down: one by one
+                            launched.append((kind, key, chunk, e))
+                stream.synchronize()
+            for kind, key, chunk, state in launched:
+                if isinstance(state, Exception):
+                    self._one_by_one(kind, key, chunk)
+                    continue
+                try:
+                    getattr(self, "_scatter_" + kind)(key, chunk, state)
+                except Exception as e:  # pragma: no cover - defensive: never leave a caller waiting
+                    for r in chunk:
+                        if not r.future.done():
+                            r.future.set_exception(e)
+            self.stats["busy_s"] += time.perf_counter() - t0
+
+    def _one_by_one(self, kind: str, key: Tuple, chunk: List[_Request]):
+        """Fallback when a batched launch was refused: each request through the blocking single-query path, so that
+        only the request that is actually at fault fails."""
+        for r in chunk:
+            try:
+                if kind == "fuse":
+                    r.future.set_result(self.mgr._fuse_rows_blocking(r.payload, key))
+                else:
+                    coll_name, top_k, expr, params_key = key
+                    r.future.set_result(self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
+            except Exception as e:
+                r.future.set_exception(e)
+
+    # ------------------------------------------------------------------ dense
+    def _enqueue_dense(self, torch, dev, stream, key, chunk):
+        coll_name, top_k, expr, _ = key
+        handle = self.mgr.collections[coll_name].handle.first
+        B = len(chunk)
+        on_dev = [hasattr(r.payload, "is_cuda") and r.payload.is_cuda for r in chunk]
+        if all(on_dev):
+            q = torch.stack([r.payload.reshape(-1).to(torch.float32) for r in chunk]).contiguous()
+        else:
+            host = np.stack([np.asarray(r.payload.detach().cpu().numpy() if hasattr(r.payload, "detach") else r.payload,
+                                        dtype=np.float32).reshape(-1) for r in chunk])
+            if host.shape[1] != handle.dim:
+                raise ValueError(f"query dim {host.shape[1]} != shard dim {handle.dim}")
+            q = torch.from_numpy(host).to(dev)
+        ids = torch.empty((B, top_k), dtype=torch.int64, device=dev)
+        sc = torch.empty((B, top_k), dtype=torch.float32, device=dev)
+        fl = torch.zeros((B,), dtype=torch.int32, device=dev)
+        mask = self.mgr._device_row_mask(expr, "dense")
+        handle.search_dense_dev(q.data_ptr(), B, top_k, ids.data_ptr(), sc.data_ptr(), fl.data_ptr(),
+                                mask.data_ptr() if mask is not None else 0, stream.cuda_stream)
+        self.stats["dense_launches"] += 1
+        return {"ids": ids, "sc": sc, "fl": fl, "keep": (q, mask)}
+
+    def _scatter_dense(self, key, chunk, st):
+        self._scatter_lists(key, chunk, st)
+
+    # ------------------------------------------------------------------ sparse
+    def _enqueue_sparse(self, torch, dev, stream, key, chunk):
+        coll_name, top_k, expr, params_key = key
+        handle = self.mgr.collections[coll_name].handle.first
+        drop = float(dict(params_key).get("drop_ratio_search", 0.0))
+        ptr, idx, val, max_nnz = pack_sparse_queries([r.payload for r in chunk], drop, handle.sparse_dim)
+        B = len(chunk)
+        d_ptr, d_idx, d_val = torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(val).to(dev)
+        ids = torch.empty((B, top_k), dtype=torch.int64, device=dev)
+        sc = torch.empty((B, top_k), dtype=torch.float32, device=dev)
+        fl = torch.zeros((B,), dtype=torch.int32, device=dev)
+        mask = self.mgr._device_row_mask(expr, "sparse")
+        handle.search_sparse_dev(d_ptr.data_ptr(), d_idx.data_ptr() if idx.size else 0, d_val.data_ptr() if idx.size else 0, B,
+                                 int(idx.shape[0]), int(max_nnz), top_k, ids.data_ptr(), sc.data_ptr(), fl.data_ptr(),
+                                 mask.data_ptr() if mask is not None else 0, stream.cuda_stream)
+        self.stats["sparse_launches"] += 1
+        return {"ids": ids, "sc": sc, "fl": fl, "keep": (d_ptr, d_idx, d_val, mask)}
+
+    def _scatter_sparse(self, key, chunk, st):
+        self._scatter_lists(key, chunk, st)
+
+    def _scatter_lists(self, key, chunk, st):
+        coll_name, top_k, expr, params_key = key
+        ids, sc, fl = st["ids"].cpu().numpy(), st["sc"].cpu().numpy(), st["fl"].cpu().numpy()
+        for i, r in enumerate(chunk):
+            try:
+                if fl[i] != 1:  # ties at the candidate cut: the host form widens the candidate set until the proof holds
+                    self.stats["redone_unproven"] += 1
+                    r.future.set_result(self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
+                else:
+                    r.future.set_result((ids[i], sc[i]))
+            except Exception as e:
+                r.future.set_exception(e)
+
+    # ------------------------------------------------------------------ fuse
+    def _enqueue_fuse(self, torch, dev, stream, key, chunk):
+        from . import _native as nat
+        wa, wb, wc, rrf_k = key
+        B = len(chunk)
+        ka = max(1, max(len(r.payload[0]) for r in chunk))
+        kb = max(len(r.payload[1]) for r in chunk)
+        kc = max(len(r.payload[2]) for r in chunk)
+        host = np.full((B, ka + kb + kc), -1, dtype=np.int64)
+        for i, r in enumerate(chunk):
+            a, b, c = r.payload
+            host[i, :len(a)] = a
+            host[i, ka:ka + len(b)] = b
+            host[i, ka + kb:ka + kb + len(c)] = c
+        d = torch.from_numpy(host).to(dev)
+        la = d[:, :ka].contiguous()
+        lb = d[:, ka:ka + kb].contiguous() if kb else None
+        lc = d[:, ka + kb:].contiguous() if kc else None
+        total = ka + kb + kc
+        oi = torch.empty((B, total), dtype=torch.int64, device=dev)
+        os_ = torch.empty((B, total), dtype=torch.float64, device=dev)
+        om = torch.empty((B, total), dtype=torch.int32, device=dev)
+        on = torch.empty((B,), dtype=torch.int32, device=dev)
+        nat.fuse_rrf_dev(la.data_ptr(), ka, lb.data_ptr() if kb else 0, kb, lc.data_ptr() if kc else 0, kc, B, wa, wb, wc,
+                         rrf_k, total, oi.data_ptr(), os_.data_ptr(), om.data_ptr(), on.data_ptr(), stream.cuda_stream)
+        self.stats["fuse_launches"] += 1
+        return {"oi": oi, "os": os_, "om": om, "on": on, "keep": (la, lb, lc)}
+
+    def _scatter_fuse(self, key, chunk, st):
+        oi, os_, om, on = st["oi"].cpu().numpy(), st["os"].cpu().numpy(), st["om"].cpu().numpy(), st["on"].cpu().numpy()
+        for i, r in enumerate(chunk):
+            n = int(on[i])
+            r.future.set_result((oi[i, :n].copy(), os_[i, :n].copy(), om[i, :n].copy()))

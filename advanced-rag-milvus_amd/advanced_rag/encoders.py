@@ -228,6 +228,15 @@ class SentenceEncoder(_Base):
             out.append(self.module(ids, types, mask))
         return torch.cat(out) if out else torch.zeros((0, self.dim), device=self.device)
 
+    @torch.inference_mode()
+    def encode_domain_to_device(self, texts: Sequence[str], domain: Optional[str] = None) -> torch.Tensor:
+        """Device counterpart of encode_domain for a batch: float32 [n, domain_dim] on the encoder's device."""
+        v = self.encode_to_device([f"{domain}: {t}" if domain else t for t in texts])
+        if self.domain_dim == self.dim:
+            return v
+        reps = -(-self.domain_dim // self.dim)
+        return v.repeat(1, reps)[:, : self.domain_dim].contiguous()
+
     def encode_semantic_batch(self, texts: Sequence[str]) -> List[np.ndarray]:
         return list(self.encode_to_device(list(texts)).cpu().numpy())
 

@@ -36,7 +36,7 @@ import numpy as np
 from . import filters as _filters
 from .constants import IndexingConstants
 from .embedding_cache import get_semantic_cache
-from .shards import ShardSet
+from .shards import PartialAppend, ShardSet
 
 logger = logging.getLogger(__name__)
 
@@ -108,7 +108,7 @@ class MilvusIndexManager:
     def __init__(self, host: str = "localhost", port: int = 19530, enable_sharding: bool = True, num_shards: int = 4,
                  semantic_dim: int = 1536, sparse_dim: int = 10000, domain_dim: int = 768, connect: bool = True,
                  *, dtype: str = "float16", device: int = 0, devices: Optional[Sequence[int]] = None,
-                 enable_domain: bool = True, device_embedding_cache: int = 0):
+                 enable_domain: bool = True, device_embedding_cache: int = 0, coalesce: bool = True):
         self.host, self.port = host, port
         self.enable_sharding, self.num_shards = enable_sharding, num_shards
         self.semantic_dim, self.sparse_dim, self.domain_dim = semantic_dim, sparse_dim, domain_dim
@@ -134,6 +134,12 @@ class MilvusIndexManager:
         # (no host hop), a miss encodes once (on the device when the generator offers encode_to_device).
         self._dev_cache_slots = int(device_embedding_cache)
         self._dev_cache = None
+        # concurrent search() calls are packed into batched device searches (batching.SearchCoalescer): the counterpart
+        # of the Milvus server's request queue (reference indexing.py:503-506 fires one RPC per call and the server
+        # batches).  coalesce=False keeps the round-2 behaviour: every call its own scan of the shard.
+        self.coalesce = bool(coalesce)
+        self._front = None
+        self._dev_masks: Dict[Any, Any] = {}   # (expr, rows, delete epoch, kind) -> packed row mask in HBM
         if connect:
             self._connect()
             self._initialize_collections()
@@ -271,18 +277,45 @@ class MilvusIndexManager:
     # ------------------------------------------------------------------ ingest
     async def index_chunks(self, chunks: List["Chunk"], domain: Optional[str] = None) -> Dict[str, Any]:
         """Embed and append chunks to every collection (reference indexing.py:264-437);
-        same summary keys, same best-effort handling of sparse/domain failures."""
+        same summary keys, same best-effort handling of sparse/domain failures.
+
+        When the embedding generator offers `encode_to_device` (encoders.SentenceEncoder) the dense rows never leave
+        the GPU: the encoder's output tensor is cast to the shard's storage type on the device and re-tiled into the
+        shard by hr_add_dense_raw_dev on the encoder's stream; the host semantic cache is not
+        consulted or filled on that path (it holds host arrays).  Sparse payloads of all chunks of a call travel as ONE
+        CSR, and every collection is flushed once per call.  `timing_ms` in the summary is an addition to the
+        reference's keys: encoder / append / flush wall time of this call."""
+        import time as _time
         summary = {"total_chunks": len(chunks), "indexed_semantic": 0, "indexed_sparse": 0, "indexed_domain": 0,
                    "errors": []}
+        timing = {"encode": 0.0, "append": 0.0, "flush": 0.0}
         use_sparse = "sparse_index" in self.collections and os.getenv("ENABLE_SPARSE", "1") == "1"
-        dense_vecs = await self._generate_semantic_embeddings_batch([c.text for c in chunks])
-        rows_dense, rows_domain, sp_ptr, sp_idx, sp_val, kept = [], [], [0], [], [], []
+        gen = self.embedding_generator
+        on_device = gen is not None and hasattr(gen, "encode_to_device") and self._main is not None and \
+            hasattr(self._main, "handles")
+        t0 = _time.perf_counter()
+        texts = [c.text for c in chunks]
+        dense_dev = dom_dev = None
+        if on_device and chunks:
+            dense_dev = await self._run_encoder(gen.encode_to_device, texts)
+            if dense_dev.dim() != 2 or dense_dev.shape[1] != self.semantic_dim:
+                raise ValueError(f"semantic embedding has dim {tuple(dense_dev.shape)[1:]}, expected {self.semantic_dim}")
+            if "domain_index" in self.collections and hasattr(gen, "encode_domain_to_device"):
+                dom_dev = await self._run_encoder(gen.encode_domain_to_device, texts, domain)
+                if dom_dev.shape[1] != self.domain_dim:
+                    raise ValueError(f"domain embedding has dim {dom_dev.shape[1]}, expected {self.domain_dim}")
+            dense_vecs = None
+        else:
+            dense_vecs = await self._generate_semantic_embeddings_batch(texts)
+        rows_dense, rows_domain, sp_ptr, sp_idx, sp_val, kept, kept_idx = [], [], [0], [], [], [], []
         n_sparse_ok = 0
         for i, chunk in enumerate(chunks):
             try:
-                dense = np.asarray(dense_vecs[i], dtype=np.float32).reshape(-1)
-                if dense.shape[0] != self.semantic_dim:
-                    raise ValueError(f"semantic embedding has dim {dense.shape[0]}, expected {self.semantic_dim}")
+                dense = None
+                if dense_vecs is not None:
+                    dense = np.asarray(dense_vecs[i], dtype=np.float32).reshape(-1)
+                    if dense.shape[0] != self.semantic_dim:
+                        raise ValueError(f"semantic embedding has dim {dense.shape[0]}, expected {self.semantic_dim}")
                 sp = None
                 if use_sparse:
                     try:
@@ -292,7 +325,7 @@ class MilvusIndexManager:
                         summary["errors"].append({"chunk_id": chunk.metadata.chunk_id,
                                                   "error": f"sparse_embedding_failed: {e}"})
                 dom = None
-                if "domain_index" in self.collections:
+                if "domain_index" in self.collections and dom_dev is None:
                     dom = np.asarray(await self._generate_domain_embedding(chunk.text, domain),
                                      dtype=np.float32).reshape(-1)
                     if dom.shape[0] != self.domain_dim:
@@ -300,7 +333,8 @@ class MilvusIndexManager:
             except Exception as e:
                 summary["errors"].append({"chunk_id": chunk.metadata.chunk_id, "error": str(e)})
                 continue
-            rows_dense.append(dense)
+            if dense is not None:
+                rows_dense.append(dense)
             if dom is not None:
                 rows_domain.append(dom)
             if use_sparse:  # a row per chunk keeps row numbers aligned across collections
@@ -309,8 +343,19 @@ class MilvusIndexManager:
                 sp_val.append(sv)
                 sp_ptr.append(sp_ptr[-1] + len(si))
             kept.append(chunk)
+            kept_idx.append(i)
+        timing["encode"] = (_time.perf_counter() - t0) * 1e3
+        summary["timing_ms"] = timing
         if not kept:
             return summary
+
+        def device_rows(t, store_half: bool):
+            """The kept rows of an encoder output, in the shard's storage type, still on the device."""
+            import torch
+            if len(kept_idx) != t.shape[0]:
+                t = t.index_select(0, torch.as_tensor(kept_idx, device=t.device))
+            return t.to(torch.float16 if store_half else torch.float32).contiguous()
+
         try:
             if "semantic_index" not in self.collections:
                 raise KeyError("semantic_index")
@@ -318,9 +363,19 @@ class MilvusIndexManager:
             if use_sparse:
                 sparse_csr = (np.asarray(sp_ptr, np.int64), np.concatenate(sp_idx) if sp_idx else np.zeros(0, np.int32),
                               np.concatenate(sp_val) if sp_val else np.zeros(0, np.float32))
+            store_half = self.dtype in ("float16", "fp16", "f16")
+            t1 = _time.perf_counter()
             # dense rows, sparse rows and payload columns of a chunk share one row number: the three are appended
             # together, and whatever fails afterwards is padded rather than left short
-            _, _, sparse_err = await asyncio.to_thread(self._main.add, np.stack(rows_dense), sparse_csr)
+            dense_rows = device_rows(dense_dev, store_half) if dense_dev is not None else np.stack(rows_dense)
+            try:
+                _, _, sparse_err = await asyncio.to_thread(self._main.add, dense_rows, sparse_csr)
+            except PartialAppend as pa:
+                # some shards took their piece before another refused: the payload of exactly those rows goes in, so
+                # that later batches keep the row numbers the shards gave them
+                self._append_payload(kept[: pa.end - pa.base])
+                summary["indexed_semantic"] = pa.end - pa.base
+                raise pa.cause
             self._append_payload(kept)
             summary["indexed_semantic"] = len(kept)
             if use_sparse:
@@ -330,14 +385,21 @@ class MilvusIndexManager:
                     logger.warning("Sparse insert failed; continuing without sparse index: %s", sparse_err)
                     summary["errors"].append({"insert_sparse_error": str(sparse_err)})
             if "domain_index" in self.collections:
+                before = self._domain.num_rows
                 try:
-                    await asyncio.to_thread(self._domain.add, np.stack(rows_domain))
-                    summary["indexed_domain"] = len(rows_domain)
+                    dom_rows = device_rows(dom_dev, store_half) if dom_dev is not None else np.stack(rows_domain)
+                    await asyncio.to_thread(self._domain.add, dom_rows)
+                    summary["indexed_domain"] = len(kept)
                 except Exception as e:  # zero rows never match (cosine 0): the domain collection stays row-aligned
-                    await asyncio.to_thread(self._domain.add, np.zeros((len(kept), self.domain_dim), np.float32))
+                    missing = len(kept) - (self._domain.num_rows - before)   # pad only what did not go in
+                    if missing > 0:
+                        await asyncio.to_thread(self._domain.add, np.zeros((missing, self.domain_dim), np.float32))
                     summary["errors"].append({"insert_domain_error": str(e)})
+            timing["append"] = (_time.perf_counter() - t1) * 1e3
+            t2 = _time.perf_counter()
             for coll in {id(c.handle): c for c in self.collections.values()}.values():
                 await asyncio.to_thread(coll.flush)
+            timing["flush"] = (_time.perf_counter() - t2) * 1e3
         except Exception as e:
             summary["errors"].append({"insert_error": str(e)})
         return summary
@@ -358,6 +420,7 @@ class MilvusIndexManager:
             c["metadata_json"].append(str(m.to_dict())[:10000])
         self._np_cols = None
         self._mask_cache.clear()
+        self._dev_masks.clear()
 
     def add_rows(self, dense: np.ndarray, sparse_csr=None, ids: Optional[Sequence[str]] = None,
                  contents: Optional[Sequence[str]] = None, **scalar_columns):
@@ -381,6 +444,7 @@ class MilvusIndexManager:
             c[name].extend([_f32(v) for v in vals] if name in _FLOAT_FIELDS else vals)
         self._np_cols = None
         self._mask_cache.clear()
+        self._dev_masks.clear()
         if sparse_err is not None:  # the rows are in (with empty sparse rows); the caller still hears about it
             raise sparse_err
 
@@ -439,6 +503,7 @@ class MilvusIndexManager:
                 self._cols[k] = z[f"col_{k}"].tolist()
         self._np_cols = None
         self._mask_cache.clear()
+        self._dev_masks.clear()
 
     # ------------------------------------------------------------------ search
     @staticmethod
@@ -493,28 +558,35 @@ class MilvusIndexManager:
                         "_row": row})
         return out
 
-    def _search_blocking(self, query_embedding, collection_name: str, top_k: int, filters: Optional[str],
-                         search_params: Optional[Dict]) -> List[Dict[str, Any]]:
-        coll = self.collections[collection_name]
-        mask = self._row_mask(filters)
+    def _search_params(self, coll, search_params: Optional[Dict]) -> Dict:
         params = search_params or ({"metric_type": "IP"} if coll.kind == "sparse"
                                    else {"metric_type": "COSINE", "params": {"ef": 64}})
         metric = params.get("metric_type", coll.metric)
         if metric != coll.metric:
-            raise ValueError(f"metric_type {metric} does not match collection {collection_name} ({coll.metric})")
+            raise ValueError(f"metric_type {metric} does not match collection {coll.name} ({coll.metric})")
+        return params
+
+    def _search_lists_blocking(self, query, collection_name: str, top_k: int, filters: Optional[str], params: Dict):
+        """(row ids [k], scores [k]) of ONE query through the host forms (which escalate until the list is proven)."""
+        coll = self.collections[collection_name]
+        mask = self._row_mask(filters)
         if coll.kind == "sparse":
-            idx, val = self._as_sparse_payload(query_embedding)
-            drop = float((params.get("params") or {}).get("drop_ratio_search", 0.0))
-            ids, sc = coll.handle.search_sparse([(idx, val)], top_k, drop, mask)
-        elif (hasattr(query_embedding, "is_cuda") and query_embedding.is_cuda and mask is None
-              and coll.handle.n_shards == 1):
-            ids, sc = self._search_dense_device(coll.handle.first, query_embedding, top_k)
+            drop = float((params.get("params") or params).get("drop_ratio_search", 0.0))
+            ids, sc = coll.handle.search_sparse([query], top_k, drop, mask)
+        elif hasattr(query, "is_cuda") and query.is_cuda and mask is None and coll.handle.n_shards == 1:
+            ids, sc = self._search_dense_device(coll.handle.first, query, top_k)
         else:
-            if hasattr(query_embedding, "detach"):
-                query_embedding = query_embedding.detach().cpu().numpy()
-            q = np.asarray(query_embedding, dtype=np.float32).reshape(1, -1)
-            ids, sc = coll.handle.search_dense(q, top_k, mask)
-        return self._format_hits(ids[0], sc[0])
+            if hasattr(query, "detach"):
+                query = query.detach().cpu().numpy()
+            ids, sc = coll.handle.search_dense(np.asarray(query, dtype=np.float32).reshape(1, -1), top_k, mask)
+        return ids[0], sc[0]
+
+    def _search_blocking(self, query_embedding, collection_name: str, top_k: int, filters: Optional[str],
+                         search_params: Optional[Dict]) -> List[Dict[str, Any]]:
+        coll = self.collections[collection_name]
+        params = self._search_params(coll, search_params)
+        query = self._as_sparse_payload(query_embedding) if coll.kind == "sparse" else query_embedding
+        return self._format_hits(*self._search_lists_blocking(query, collection_name, top_k, filters, params))
 
     @staticmethod
     def _search_dense_device(handle, q_dev, top_k: int):
@@ -532,11 +604,55 @@ class MilvusIndexManager:
             return handle.search_dense(q.cpu().numpy(), top_k)
         return ids.cpu().numpy(), sc.cpu().numpy()
 
+    # ---- coalescing front (batching.py) -------------------------------------------------------------------------
+    def _coalescer(self, coll):
+        """The batching front, or None when this collection cannot use it (spread over several shard handles: those
+        searches fan out per shard and merge on the host)."""
+        if not self.coalesce or getattr(coll.handle, "n_shards", 1) != 1 or not hasattr(coll.handle, "handles"):
+            return None
+        if self._front is None:
+            from .batching import SearchCoalescer
+            self._front = SearchCoalescer(self)
+        return self._front
+
+    def _device_row_mask(self, expr: Optional[str], kind: str):
+        """Packed row mask of a filter expression (+ tombstones) as a uint8 CUDA tensor, kept per (expression, rows,
+        tombstone epoch): a batch of filtered searches uploads nothing.  None = all rows."""
+        keep = self._row_mask(expr)
+        if keep is None:
+            return None
+        key = (expr, self.num_rows, self._delete_epoch, kind)
+        hit = self._dev_masks.get(key)
+        if hit is None:
+            import torch
+            n_local = self._main.first.num_sparse_rows if kind == "sparse" else self._main.first.num_rows
+            packed = np.packbits(keep, bitorder="little")
+            need = (n_local + 7) // 8
+            if packed.size < need:
+                raise ValueError(f"row mask has {packed.size} bytes, the collection's {n_local} rows need {need}")
+            if len(self._dev_masks) >= 16:
+                self._dev_masks.pop(next(iter(self._dev_masks)))
+            hit = self._dev_masks[key] = torch.from_numpy(packed).to(f"cuda:{self.device}")
+        return hit
+
+    @staticmethod
+    def _params_key(params: Dict) -> tuple:
+        return tuple(sorted((k, v) for k, v in (params.get("params") or {}).items() if isinstance(v, (int, float, str, bool))))
+
     async def search(self, query_embedding, collection_name: str, top_k: int = 20, filters: Optional[str] = None,
                      search_params: Optional[Dict] = None) -> List[Dict[str, Any]]:
         if collection_name not in self.collections:
             raise ValueError(f"Collection {collection_name} not found")
+        coll = self.collections[collection_name]
+        front = self._coalescer(coll)
         try:
+            if front is not None:
+                params = self._search_params(coll, search_params)
+                query = self._as_sparse_payload(query_embedding) if coll.kind == "sparse" else query_embedding
+                fut = front.submit("sparse" if coll.kind == "sparse" else "dense",
+                                   (collection_name, int(top_k), filters, self._params_key(params)), query)
+                ids, sc = await asyncio.wait_for(asyncio.wrap_future(fut), timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)
+                return self._format_hits(ids, sc)
             return await asyncio.wait_for(
                 asyncio.to_thread(self._search_blocking, query_embedding, collection_name, top_k, filters,
                                   search_params),
@@ -545,21 +661,45 @@ class MilvusIndexManager:
             logging.error("shard search timeout for collection %s", collection_name)
             raise Exception(f"Search timeout for collection {collection_name}")
 
+    @staticmethod
+    def _fuse_inputs(row_lists, id_lists, weights, rrf_k):
+        row_to_id = {}
+        for rows, ids in zip(row_lists, id_lists):
+            for r, i in zip(rows, ids):
+                row_to_id.setdefault(int(r), i)
+        lists = tuple([np.asarray(r, dtype=np.int64) for r in row_lists] + [np.zeros(0, np.int64)] * (3 - len(row_lists)))
+        w = list(weights) + [0.0] * (3 - len(weights))
+        return row_to_id, lists, (float(w[0]), float(w[1]), float(w[2]), int(rrf_k))
+
+    @staticmethod
+    def _fuse_output(row_to_id, rows, scores, methods):
+        return [(row_to_id[int(r)], float(s), [b for b in range(3) if (int(m) >> b) & 1])
+                for r, s, m in zip(rows, scores, methods)]
+
+    def _fuse_rows_blocking(self, lists, key):
+        wa, wb, wc, rrf_k = key
+        return self._main.first.fuse_rrf(lists[0], lists[1], lists[2], wa, wb, wc, rrf_k)
+
     def fuse_rank_lists(self, row_lists: Sequence[Sequence[int]], id_lists: Sequence[Sequence[Any]],
                         weights: Sequence[float], rrf_k: int = 60):
         """RRF on the device (csrc/fuse.h) over row numbers; returns
         [(id, float64 score, [list indices])] in fused order."""
         if self._main is None:
             raise RuntimeError("no shard handle")
-        row_to_id = {}
-        for rows, ids in zip(row_lists, id_lists):
-            for r, i in zip(rows, ids):
-                row_to_id.setdefault(int(r), i)
-        lists = [np.asarray(r, dtype=np.int64) for r in row_lists] + [np.zeros(0, np.int64)] * (3 - len(row_lists))
-        w = list(weights) + [0.0] * (3 - len(weights))
-        rows, scores, methods = self._main.first.fuse_rrf(lists[0], lists[1], lists[2], w[0], w[1], w[2], rrf_k)
-        return [(row_to_id[int(r)], float(s), [b for b in range(3) if (int(m) >> b) & 1])
-                for r, s, m in zip(rows, scores, methods)]
+        row_to_id, lists, key = self._fuse_inputs(row_lists, id_lists, weights, rrf_k)
+        return self._fuse_output(row_to_id, *self._fuse_rows_blocking(lists, key))
+
+    async def fuse_rank_lists_async(self, row_lists, id_lists, weights, rrf_k: int = 60):
+        """The same fusion for a caller on the event loop: concurrent callers share one hr_fuse_rrf_dev launch."""
+        if self._main is None:
+            raise RuntimeError("no shard handle")
+        row_to_id, lists, key = self._fuse_inputs(row_lists, id_lists, weights, rrf_k)
+        front = self._coalescer(self.collections["semantic_index"]) if "semantic_index" in self.collections else None
+        if front is None or max(len(x) for x in lists) > 256:
+            return self._fuse_output(row_to_id, *await asyncio.to_thread(self._fuse_rows_blocking, lists, key))
+        rows, scores, methods = await asyncio.wait_for(asyncio.wrap_future(front.submit("fuse", key, lists)),
+                                                       timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)
+        return self._fuse_output(row_to_id, rows, scores, methods)
 
     # ------------------------------------------------------------------ embeddings
     async def _run_encoder(self, fn, *args):
@@ -662,6 +802,10 @@ class MilvusIndexManager:
             self.collections[collection_name].delete(expr)
 
     async def close(self):
+        if self._front is not None:
+            await asyncio.to_thread(self._front.close)
+            self._front = None
+        self._dev_masks.clear()
         for h in (self._main, self._domain):
             if h is not None:
                 try:

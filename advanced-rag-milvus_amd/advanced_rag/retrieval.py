@@ -192,8 +192,7 @@ class HybridRetriever:
             except Exception:
                 pass
 
-        fused = self._fuse_results(semantic_results=hit_lists[0], sparse_results=hit_lists[1],
-                                   domain_results=hit_lists[2] if len(hit_lists) > 2 else [])
+        fused = await self._fuse_results_async(hit_lists[0], hit_lists[1], hit_lists[2] if len(hit_lists) > 2 else [])
         for hit in fused:
             meta = hit.get("metadata")
             if isinstance(meta, dict):
@@ -246,6 +245,27 @@ class HybridRetriever:
                       domain_results: Optional[List[Dict]] = None) -> List[Dict[str, Any]]:
         hit_lists = [semantic_results or [], sparse_results or [], domain_results or []]
         weights = [self.config.dense_weight, self.config.sparse_weight, self.DOMAIN_WEIGHT]
+        return self._assemble_fused(hit_lists, self._rank_fusion(hit_lists, weights))
+
+    async def _fuse_results_async(self, semantic_results, sparse_results, domain_results=None) -> List[Dict[str, Any]]:
+        """_fuse_results for a caller on the event loop: with the HBM index manager the rank fusion of concurrent
+        retrieve() calls shares one device launch (index_manager.fuse_rank_lists_async); same arithmetic, same result."""
+        hit_lists = [semantic_results or [], sparse_results or [], domain_results or []]
+        weights = [self.config.dense_weight, self.config.sparse_weight, self.DOMAIN_WEIGHT]
+        device_fuse = getattr(self.index_manager, "fuse_rank_lists_async", None)
+        ranked = None
+        if device_fuse is not None:
+            rows = [[h.get("_row") for h in hits] for hits in hit_lists]
+            if all(r is not None for lst in rows for r in lst) and any(rows):
+                try:
+                    ranked = await device_fuse(rows, [[h["id"] for h in hits] for hits in hit_lists], list(weights), self.RRF_K)
+                except Exception:  # pragma: no cover - fall through to the host arithmetic
+                    logger.exception("device rank fusion failed; using host arithmetic")
+        if ranked is None:
+            ranked = self._rank_fusion(hit_lists, weights)
+        return self._assemble_fused(hit_lists, ranked)
+
+    def _assemble_fused(self, hit_lists, ranked) -> List[Dict[str, Any]]:
         # payload of an id = the hit from the semantic list if present (overwritten
         # by a later semantic duplicate), else the first sparse/domain hit
         payload: Dict[Any, Dict] = {}
@@ -257,7 +277,7 @@ class HybridRetriever:
 
         now = datetime.utcnow()
         fused: List[Dict[str, Any]] = []
-        for doc_id, score, seen_in in self._rank_fusion(hit_lists, weights):
+        for doc_id, score, seen_in in ranked:
             hit = payload[doc_id]
             hit.pop("_row", None)  # manager-internal row number (device rank fusion); not part of the reference's hit dict
             hit["score"] = score

@@ -39,6 +39,14 @@ def merge_lists(ids: Sequence[np.ndarray], scores: Sequence[np.ndarray], k: int)
     return out_ids, out_sc
 
 
+class PartialAppend(RuntimeError):
+    """A multi-shard append failed after some pieces had gone in: global rows [base, end) exist in the shards."""
+
+    def __init__(self, base: int, end: int, cause: Exception):
+        super().__init__(f"append stopped after rows [{base}, {end}): {cause}")
+        self.base, self.end, self.cause = base, end, cause
+
+
 class ShardSet:
     def __init__(self, handles: list):
         if not handles:
@@ -94,18 +102,31 @@ class ShardSet:
             pieces.append((s, lo, n))
         return pieces
 
-    def add(self, dense: Optional[np.ndarray], sparse_csr=None, n: Optional[int] = None):
+    def add(self, dense, sparse_csr=None, n: Optional[int] = None):
         """Append rows (dense [n, dim] and/or a CSR triple of n rows) to the shards; both parts of a row go to the
-        same shard.  Returns (base, end, sparse_error): the global row range [base, end) and, if a shard refused
+        same shard.  `dense` is a numpy array (host rows, uploaded) or a CUDA tensor already in the shard's storage
+        dtype (an encoder's output: re-tiled device to device by hr_add_dense_raw_dev, no host hop).
+        Returns (base, end, sparse_error): the global row range [base, end) and, if a shard refused
         the sparse part of its piece, that error — the piece then got EMPTY sparse rows instead, because the row
-        number is the only join key between the dense rows, the sparse rows and the host payload columns."""
+        number is the only join key between the dense rows, the sparse rows and the host payload columns.
+        A dense failure part-way (say, one device out of memory) raises PartialAppend carrying the rows that did go
+        in, so that the caller can keep its payload columns aligned with them."""
         n = dense.shape[0] if dense is not None else (len(sparse_csr[0]) - 1 if sparse_csr is not None else int(n or 0))
         base = self._n
         sparse_error = None
+        on_device = dense is not None and hasattr(dense, "is_cuda")
         for s, lo, hi in self._pieces(n):
             h = self.handles[s]
             if dense is not None:
-                h.add_dense(dense[lo:hi])
+                try:
+                    if on_device:
+                        self._add_dense_device(h, dense[lo:hi])
+                    else:
+                        h.add_dense(dense[lo:hi])
+                except Exception as e:
+                    if self._n > base:   # earlier pieces are in: tell the caller how many rows the set gained
+                        raise PartialAppend(base, self._n, e) from e
+                    raise
             if sparse_csr is not None:
                 ptr, idx, val = sparse_csr
                 ptr = np.asarray(ptr, dtype=np.int64)
@@ -117,6 +138,21 @@ class ShardSet:
             self.rows_of[s] = np.concatenate([self.rows_of[s], np.arange(base + lo, base + hi, dtype=np.int64)])
             self._n = base + hi  # pieces are in row order: a failure further on leaves a consistent prefix
         return base, base + n, sparse_error
+
+    @staticmethod
+    def _add_dense_device(h, rows):
+        """rows: CUDA tensor [m, dim] in the shard's storage dtype (fp16 / fp32); copied to the shard's GPU if needed."""
+        import torch
+        want = torch.float16 if h.dtype == 1 else torch.float32
+        if rows.dtype != want:
+            raise ValueError(f"device rows are {rows.dtype}, the shard stores {want}")
+        if rows.dim() != 2 or rows.shape[1] != h.dim:
+            raise ValueError(f"rows must be [n,{h.dim}], got {tuple(rows.shape)}")
+        if rows.device.index != h.device:
+            rows = rows.to(f"cuda:{h.device}")
+        rows = rows.contiguous()
+        stream = torch.cuda.current_stream(rows.device)
+        h.add_dense_dev(rows.data_ptr(), rows.shape[0], stream.cuda_stream)   # synchronises the stream before it returns
 
     def finalize(self):
         for h in self.handles:

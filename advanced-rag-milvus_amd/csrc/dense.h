@@ -965,20 +965,45 @@ __device__ inline bool refine_dense_slot(const chunk_t* __restrict__ tiles, int 
     if (valid && rowmask) valid = (rowmask[row >> 3] >> (row & 7)) & 1;
     if (!valid) return false;
     double s = 0.0;
-    // The fp64 add chain is serial by definition (canonical k order); the loads are not:
-    // fetch one whole 1 KiB-tile row slice (4 chunks) x 2 tiles per round trip.
-    constexpr int U = 8;
-    for (int kc0 = 0; kc0 < KT * 4; kc0 += U) {   // KT*4 is a multiple of 16
-        union { chunk_t v; STORE e[EPC]; } c[U];
+    // The fp64 add chain is serial by definition (canonical k order); the loads are not: one whole 1 KiB-tile row
+    // slice (4 chunks) x 2 tiles per round trip, and the NEXT round's 8 chunks are requested before this round's are
+    // consumed (the fused finishing kernel runs 8 waves per compute unit: nothing else hides the round trip).
+    // (the next round is requested in two halves, each right after the half of the current round it replaces has been
+    // consumed: 8 to 12 chunks in flight on 48 registers instead of 64)
+    constexpr int U = 8, H = U / 2;
+    const int n_kc = KT * 4;   // a multiple of 16
+    union Chunk { chunk_t v; STORE e[EPC]; };
+    Chunk lo[H], hi[H], nlo[H];
+    auto consume = [&](const Chunk (&c)[H], int kc_first) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) c[u].v = tiles[chunk_index(row, kc0 + u, KT)];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < H; ++u) {
 #pragma unroll
             for (int j = 0; j < EPC; ++j) {
-                const int k = (kc0 + u) * EPC + j;
+                const int k = (kc_first + u) * EPC + j;
                 if (k < dim) s = __dadd_rn(s, __dmul_rn((double)c[u].e[j], (double)qq[k]));
             }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < H; ++u) lo[u].v = tiles[chunk_index(row, u, KT)];
+#pragma unroll
+    for (int u = 0; u < H; ++u) hi[u].v = tiles[chunk_index(row, H + u, KT)];
+    for (int kc0 = 0; kc0 < n_kc; kc0 += U) {
+        const int kn = kc0 + U < n_kc ? kc0 + U : kc0;   // the last round re-reads itself (no branch around the loads)
+#pragma unroll
+        for (int u = 0; u < H; ++u) nlo[u].v = tiles[chunk_index(row, kn + u, KT)];
+        __builtin_amdgcn_sched_barrier(0);   // keep the compiler from hoisting all 16 loads above the first use
+        consume(lo, kc0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < H; ++u) lo[u].v = tiles[chunk_index(row, kn + H + u, KT)];   // next round's upper half, parked in lo
+        __builtin_amdgcn_sched_barrier(0);
+        consume(hi, kc0 + H);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < H; ++u) {
+            hi[u].v = lo[u].v;
+            lo[u].v = nlo[u].v;
         }
     }
     if (cosine) {

@@ -59,32 +59,49 @@ inline size_t finish_lds_bytes(const FinishPair& p) {
         if (m.kind == 1) {
             const size_t s = (size_t)kFilterBits / 8 + (size_t)m.q_cap * 8;
             region_b = region_b > s ? region_b : s;
+        } else {
+            const size_t s = (size_t)m.dim * 4;   // the query, staged for the refine
+            region_b = region_b > s ? region_b : s;
         }
     }
     return (size_t)p.key_slots * 8 + region_b;
 }
 
-// Bucket maxima of one query into LDS (what bucket_max_kernel writes to the global table).
+// Bucket maxima of one query into LDS (what bucket_max_kernel writes to the global table).  A wave takes
+// kFinishBucketsPerWave buckets per trip and issues all their (coalesced, 256-byte) loads before the first reduction:
+// with 8 waves per block the pass is bound by memory latency, not bytes (312 KB per query at 1.25M rows).
+constexpr int kFinishBucketsPerWave = 32;
 __device__ inline void bucket_max_block(const GroupSelArgs& a, int q, float* s_bmax) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = blockDim.x >> 6;
     const float* gm = a.gmax + (int64_t)q * a.n_groups;
-    for (int64_t b0 = (int64_t)wid * kBucketsPerWave; b0 < a.n_buckets; b0 += (int64_t)nw * kBucketsPerWave) {
-        float v[kBucketsPerWave];
+    for (int64_t b0 = (int64_t)wid * kFinishBucketsPerWave; b0 < a.n_buckets; b0 += (int64_t)nw * kFinishBucketsPerWave) {
+        float v[kFinishBucketsPerWave];
 #pragma unroll
-        for (int i = 0; i < kBucketsPerWave; ++i) {
+        for (int i = 0; i < kFinishBucketsPerWave; ++i) {
             const int64_t g = (b0 + i) * kBucketGroups + lane;
             v[i] = g < a.n_groups ? gm[g] : -__builtin_inff();
         }
         float mine = -__builtin_inff();
 #pragma unroll
-        for (int i = 0; i < kBucketsPerWave; ++i) {
+        for (int i = 0; i < kFinishBucketsPerWave; ++i) {
             const float m = wave_max(v[i]);
             if (lane == i) mine = m;
         }
-        if (lane < kBucketsPerWave && b0 + lane < a.n_buckets) s_bmax[b0 + lane] = mine;
+        if (lane < kFinishBucketsPerWave && b0 + lane < a.n_buckets) s_bmax[b0 + lane] = mine;
     }
 }
+
+// <= 88 VGPRs: two of these waves fit on a SIMD beside the two 168-register waves of a resident dense-scan block
+#ifdef HR_STAMP  // diagnostic build only (make stamp): s_memtime at the phase boundaries of block (query 0, modality m)
+__device__ unsigned long long hr_finish_stamps[2][8];
+#define FINISH_STAMP(i)                                                                      \
+    do {                                                                                     \
+        if (blockIdx.x == 0 && threadIdx.x == 0) hr_finish_stamps[blockIdx.y][i] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define FINISH_STAMP(i) do {} while (0)
+#endif
 
 __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
     extern __shared__ uint64_t finish_lds[];
@@ -98,13 +115,20 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
     uint64_t* s_key = finish_lds;
     float* s_bmax = reinterpret_cast<float*>(finish_lds + p.key_slots);
 
+    FINISH_STAMP(0);
     if (a.sel.two_level) bucket_max_block(a.sel, q, s_bmax);
     __syncthreads();
+    FINISH_STAMP(1);
     select_groups_block(a.sel, q, s_bmax, s_cand, sh, sel_bucket);
     __syncthreads();
+    FINISH_STAMP(2);
 
     if (a.kind == 0) {
-        const float* qq = a.q + (int64_t)q * a.dim;
+        // the query in LDS (the bucket maxima are no longer needed): 64 query values per round as LDS reads instead of
+        // global loads that would compete with the row chunks for registers and memory queue
+        float* qq = s_bmax;
+        for (int k = tid; k < a.dim; k += kFinishThreads) qq[k] = a.q[(int64_t)q * a.dim + k];
+        __syncthreads();
         const double qn2 = a.qn2[q];
         for (int slot = tid; slot < n_slots; slot += kFinishThreads) {
             float sc = 0.f;
@@ -133,9 +157,12 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
         }
     }
     __syncthreads();
+    FINISH_STAMP(3);
     TopkArgs t = a.topk;
     t.n = n_slots;
     select_topk_block(t, q, [&](int64_t i) -> uint64_t { return s_key[i]; }, sh, sel);
+    __syncthreads();
+    FINISH_STAMP(4);
 }
 
 }  // namespace hbmrag

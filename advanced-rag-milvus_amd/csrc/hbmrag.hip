@@ -1991,6 +1991,9 @@ int hr_set_profiling(hr_index* h, int enabled) {
 }
 
 #ifdef HR_STAMP
+HR_API int hr_debug_finish_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hbmrag::hr_finish_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
 HR_API int hr_debug_gemm_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(hbmrag::hr_gemm_stamps), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
 }

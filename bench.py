@@ -209,6 +209,13 @@ def main():
                          "queries drawn from the same distribution (SURVEY §7 'sparse skew')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-api-concurrent", action="store_true", help="skip the concurrent retrieve() measurement")
+    ap.add_argument("--ingest", action="store_true",
+                    help="measure AdvancedRAGPipeline.ingest_documents instead of the search step: synthetic documents of "
+                         "~512 tokens through SentenceEncoder (random-init, bge-base shape at --dim 768) + BM25SparseEncoder "
+                         "into an fp16 shard; the device-to-device ingest path beside the host-hop one; prints its own JSON line")
+    ap.add_argument("--ingest-docs", type=int, default=1024)
+    ap.add_argument("--ingest-batch", type=int, default=128, help="documents per ingest_documents call")
     ap.add_argument("--profile-all", action="store_true", help="bracket every kernel phase, not just the scans")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="query batches kept in flight: 1 = one batch at a time; 2..4 = scans of batch i+1 on a heavy "
@@ -224,6 +231,8 @@ def main():
     ap.add_argument("--finish-mode", choices=("auto", "chain", "fused"), default="auto",
                     help="finishing path: auto = fused kernel for batches that fill the chip, chain = five launches")
     args = ap.parse_args()
+    if args.ingest:
+        return bench_ingest(args)
 
     import torch
     import torch.distributed as dist
@@ -603,6 +612,85 @@ def main():
         dist.destroy_process_group()
 
 
+def bench_ingest(args):
+    """docs/s and chunks/s of AdvancedRAGPipeline.ingest_documents (reference pipeline.py:120-215 -> indexing.py:264-437)
+    on one GPU: host work (diagnostics, chunking, enrichment, BM25) + encoder forward + append + flush, for the
+    device-to-device dense path (encoder output -> hr_add_dense_raw_dev) and for the host-hop path
+    (.cpu().numpy() -> np.stack -> hr_add_dense) side by side."""
+    import asyncio
+    import contextlib
+    import torch
+    from advanced_rag import AdvancedRAGPipeline, BM25SparseEncoder, PipelineConfig
+    from advanced_rag.encoders import EncoderConfig, SentenceEncoder
+    from advanced_rag.embedding_cache import initialize_caches
+
+    dev = "cuda:0"
+    rng = np.random.default_rng(99)
+    vocab = [f"w{i}" for i in range(20000)]
+    zipf = 1.0 / np.arange(1, len(vocab) + 1) ** 1.05
+    zipf /= zipf.sum()
+
+    def make_doc(i):
+        words = rng.choice(len(vocab), size=512, p=zipf)
+        sents = [" ".join(vocab[w] for w in words[j:j + 16]).capitalize() + "." for j in range(0, 512, 16)]
+        return {"id": f"doc{i}", "text": " ".join(sents), "metadata": {"source": "bench"}}
+
+    docs = [make_doc(i) for i in range(args.ingest_docs)]
+    cfg = EncoderConfig(hidden=args.dim, layers=12, intermediate=4 * args.dim, heads=12) if args.dim >= 768 else \
+        EncoderConfig(hidden=args.dim)
+    bm25 = BM25SparseEncoder(sparse_dim=SPARSE_DIM).fit(d["text"] for d in docs)
+    enc = SentenceEncoder(cfg, device=dev, sparse_encoder=bm25, max_len=256, batch_size=128)
+
+    class HostHop:  # the same encoder without the device entry points: index_chunks takes the host path
+        def __init__(self, e):
+            self.e = e
+        encode_semantic = lambda self, t: self.e.encode_semantic(t)
+        encode_semantic_batch = lambda self, ts: self.e.encode_semantic_batch(ts)
+        encode_domain = lambda self, t, d=None: self.e.encode_domain(t, d)
+        encode_sparse = lambda self, t: self.e.encode_sparse(t)
+        encode_sparse_query = lambda self, t: self.e.encode_sparse_query(t)
+
+    out = {}
+    for name, gen in (("device_to_device", enc), ("host_hop", HostHop(enc))):
+        initialize_caches()
+        pipe = AdvancedRAGPipeline(config=PipelineConfig(enable_audit_logging=False), semantic_dim=args.dim,
+                                   sparse_dim=SPARSE_DIM, enable_domain=False, dtype="float16")
+        pipe.index_manager.embedding_generator = gen
+        tm = {"encode": 0.0, "append": 0.0, "flush": 0.0}
+        chunks = 0
+
+        async def run():
+            nonlocal chunks
+            for b0 in range(0, len(docs), args.ingest_batch):
+                rep_ = await pipe.ingest_documents(docs[b0:b0 + args.ingest_batch])
+                summ = rep_["indexing_summary"]
+                assert not summ["errors"], summ["errors"][:2]
+                chunks += summ["indexed_semantic"]
+                for k in tm:
+                    tm[k] += summ["timing_ms"][k]
+
+        with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+            asyncio.run(pipe.ingest_documents(docs[:16]))  # warm-up (kernels, workspaces); these rows stay in the shard
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            asyncio.run(run())
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+        rows = pipe.index_manager.get_collection_stats("semantic_index")["num_entities"]
+        out[name] = {"docs_per_s": len(docs) / wall, "chunks_per_s": chunks / wall, "wall_s": wall, "chunks": chunks,
+                     "rows_in_shard": rows, "encoder_ms": tm["encode"], "append_ms": tm["append"], "flush_ms": tm["flush"],
+                     "host_pipeline_ms": wall * 1e3 - tm["encode"] - tm["append"] - tm["flush"]}
+        asyncio.run(pipe.close())
+    print(json.dumps({"metric": "ingest_docs_per_sec", "value": out["device_to_device"]["docs_per_s"], "unit": "docs/s",
+                      "n_gpus": 1, "data": "synthetic", "dtype": "f16",
+                      "config": {"workload": f"{len(docs)} documents x ~512 tokens -> AdvancedRAGPipeline.ingest_documents, "
+                                             f"SentenceEncoder random-init hidden {args.dim} (PyTorch-ROCm fp16) + BM25, "
+                                             f"{args.ingest_batch} documents per call, fp16 shard"},
+                      "paths": out,
+                      "note": "encoder_ms includes the host-side sparse (BM25) payloads of the call; host_pipeline_ms = "
+                              "diagnostics + chunking + enrichment in Python"}))
+
+
 def ce_report(ce, events, pairs: int, T: int):
     """Forward pass of the cross-encoder leg (BASELINE config 4's rerank 20 -> 5; north_star assigns it to PyTorch-ROCm):
     device ms per step from events around the forward, its arithmetic (per token and layer 24 H^2 for the projections and
@@ -705,6 +793,57 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
 
     with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):  # the pipeline prints a line per SLA / risk warning
         lat2 = asyncio.run(run_pipeline())
+
+    # ---- the drop-in API under the reference's concurrency model: 64 / 128 in-flight pipeline.retrieve() coroutines on
+    # one event loop (service.py:136,149), with the batching front of MilvusIndexManager.search and without it
+    api = None
+    if world == 1 and not args.no_api_concurrent:
+        api = {}
+        for coalesce in (True, False):
+            m2 = MilvusIndexManager(semantic_dim=args.dim, sparse_dim=SPARSE_DIM, connect=False, coalesce=coalesce)
+            m2.attach_shards([h], synthetic_rows=h.num_rows)
+            m2.embedding_generator = Gen()
+            pipe2 = AdvancedRAGPipeline(connect_to_milvus=False, config=PipelineConfig(top_k=args.top_k))
+            pipe2.index_manager = m2
+            pipe2.retriever.index_manager = m2
+
+            async def burst(n_total, in_flight):
+                sem = asyncio.Semaphore(in_flight)
+                lat3 = []
+
+                async def one(i):
+                    async with sem:
+                        t0 = time.perf_counter()
+                        res, _m = await pipe2.retrieve(f"q{i % flatQ.shape[0]}", context={"retrieval_profile": "default"})
+                        lat3.append((time.perf_counter() - t0) * 1e3)
+                        assert 0 < len(res) <= pipe2.config.rerank_top_k
+                t0, c0 = time.perf_counter(), time.process_time()
+                await asyncio.gather(*[one(i) for i in range(n_total)])
+                return lat3, time.perf_counter() - t0, time.process_time() - c0
+
+            for in_flight in (64, 128):
+                n_total = (16 if coalesce else 2) * in_flight
+                with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+                    asyncio.run(burst(in_flight, in_flight))  # warm-up (embedding cache, workspaces)
+                    st0 = dict(m2._front.stats) if coalesce and m2._front else None
+                    lat3, wall, cpu = asyncio.run(burst(n_total, in_flight))
+                ent = {"requests": n_total, "qps": n_total / wall, "p50_ms": float(np.percentile(lat3, 50)),
+                       "p95_ms": float(np.percentile(lat3, 95)), "process_cpu_us_per_request": cpu / n_total * 1e6}
+                if st0 is not None:
+                    st1 = m2._front.stats
+                    scans = (st1["dense_launches"] + st1["sparse_launches"]) - (st0["dense_launches"] + st0["sparse_launches"])
+                    ent.update({"scan_launches_per_request": scans / n_total,
+                                "mean_queries_per_scan_launch": 2 * n_total / max(scans, 1),
+                                "front_busy_frac": (st1["busy_s"] - st0["busy_s"]) / wall,
+                                "redone_unproven": st1["redone_unproven"] - st0["redone_unproven"]})
+                else:
+                    ent["scan_launches_per_request"] = 2.0
+                api.setdefault(f"in_flight_{in_flight}", {})["coalesced" if coalesce else "uncoalesced"] = ent
+            if coalesce and m2._front is not None:
+                m2._front.close()
+            m2.embedding_executor.shutdown(wait=False)
+        api["note"] = ("AdvancedRAGPipeline.retrieve() coroutines on one event loop, host buffers in, Python result objects out; "
+                       "engine `value` above is the same kernels fed with device-resident pre-batched queries")
     if world > 1:
         mgr.stop_workers()
     mgr.embedding_executor.shutdown(wait=False)
@@ -714,7 +853,8 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
             "p95_pipeline_retrieve_ms": float(np.percentile(lat2, 95)), "latency_queries": n,
             **({"filtered_retrieve": {"filter": "chunk_index < 5 (half of the rows)", "first_request_ms": first_f,
                                       "p50_ms": float(np.percentile(lat_f, 50)), "p95_ms": float(np.percentile(lat_f, 95)),
-                                      "queries": len(lat_f)}} if lat_f else {})}
+                                      "queries": len(lat_f)}} if lat_f else {}),
+            **({"api_concurrent": api} if api else {})}
 
 
 if __name__ == "__main__":

@@ -102,9 +102,26 @@ for name, mode, prep, cus, depth in ARRANGEMENTS:
                                                out["ids"].data_ptr(), out["scores"].data_ptr(), out["flags"].data_ptr(), st.cuda_stream))
     pa = eng._post_args(out, B, eng.n_lists, out.get("gathered"))
     post_us = timed(lambda: nat.post_lists_dev(pa, B, st.cuda_stream))
+    pieces = {}
+    if eng.n_lists > 1:   # the parts of the post kernel as the separate entry points
+        g, lay = out["gathered"], out["layout"]
+        def merges():
+            for m in range(2):
+                sc_off, id_off, sc_stride, id_stride = lay.merge_args(m)
+                nat.merge_topk_dev(g.data_ptr() + sc_off, g.data_ptr() + id_off, eng.n_lists, B, 40, 40, out["m_ids"][m].data_ptr(),
+                                   out["m_scores"][m].data_ptr(), st.cuda_stream, score_stride=sc_stride, id_stride=id_stride)
+        pieces["merge_2_modalities_us"] = timed(merges)
+        pieces["fuse_us"] = timed(lambda: nat.fuse_rrf_dev(out["m_ids"][0].data_ptr(), 40, out["m_ids"][1].data_ptr(), 40, 0, 0, B, 0.7, 0.3, 0.2, 60,
+                                                           20, out["fused_ids"].data_ptr(), out["fused_scores"].data_ptr(),
+                                                           out["fused_methods"].data_ptr(), out["fused_n"].data_ptr(), st.cuda_stream))
+        pieces["rerank_us"] = timed(lambda: nat.rerank_linear_dev(out["fused_ids"].data_ptr(), out["fused_scores"].data_ptr(),
+                                                                  out["fused_methods"].data_ptr(), out["fused_n"].data_ptr(), B, 20, 1.0, 0.1,
+                                                                  0.0, 5, out["rr_ids"].data_ptr(), out["rr_scores"].data_ptr(),
+                                                                  out["rr_orig"].data_ptr(), st.cuda_stream))
+        pieces["empty_launch_pair_us"] = timed(lambda: (torch.cuda._sleep(1), torch.cuda._sleep(1)))
     print(json.dumps({"arrangement": name, "rows": N, "simulate_ranks": SIM, "depth": depth, "light_cus": cus, "prep_stream": prep,
                       "finish": {1: "chain", 2: "fused"}[mode], **res, "phases_ms": phases, "all_exact": exact,
-                      "finish_alone_us": fin_us, "post_alone_us": post_us,
+                      "finish_alone_us": fin_us, "post_alone_us": post_us, "post_pieces": pieces,
                       "dense_scan_frac_hbm": h.dense_scan_bytes / (phases.get("dense_scan", 1e9) * 1e-3) / 8e12}), flush=True)
     eng.close()
 nat.debug_option(nat.HR_DEBUG_FINISH_MODE, 0)

@@ -1,0 +1,153 @@
+"""The batching front of MilvusIndexManager.search (advanced_rag/batching.py): concurrent retrieve() coroutines —
+the reference's concurrency model, service.py:136,149 + retrieval.py:293-306 — are packed into batched device
+searches and must get exactly what sequential single-query calls get."""
+import asyncio
+
+import numpy as np
+import pytest
+
+import g5_data
+from advanced_rag import HybridRetriever, MilvusIndexManager, RetrievalConfig
+from advanced_rag.constants import RetrievalConstants
+from test_gpu_golden import _g5_manager
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture()
+def long_timeout():
+    old = RetrievalConstants.TIMEOUT_SECONDS
+    RetrievalConstants.TIMEOUT_SECONDS = 120.0
+    yield
+    RetrievalConstants.TIMEOUT_SECONDS = old
+
+
+class TableGen:
+    """Embedding generator keyed by the query text "q<i>"."""
+
+    def __init__(self, Q, SQ):
+        self.Q, self.SQ = Q, SQ
+
+    def encode_semantic(self, text):
+        return self.Q[int(text[1:])]
+
+    def encode_sparse(self, text):
+        qi, qv = self.SQ[int(text[1:])]
+        return {"indices": qi.tolist(), "values": qv.tolist()}
+
+    def encode_domain(self, text, domain=None):
+        return np.zeros(8, np.float32)
+
+
+def _strip(hits):
+    return [(h["id"], float(h["score"]).hex(), tuple(h["retrieval_methods"]), h["metadata"]["chunk_index"]) for h in hits]
+
+
+def test_g5_reference_runs_issued_concurrently(gpu, long_timeout):
+    """The 8 hybrid g5 runs of the reference, issued as concurrent coroutines through ONE manager: every coroutine gets
+    the reference's ids / fused scores / methods although its searches shared launches with the others."""
+    from advanced_rag.embedding_cache import initialize_caches
+    g, X, csr, Q, SQ = g5_data.inputs()
+    mgr = _g5_manager("float32", X, csr, True)
+    initialize_caches()
+    mgr.embedding_generator = TableGen(Q, SQ)
+    retr = HybridRetriever(mgr, RetrievalConfig(top_k=20))
+    runs = [r for r in g["runs"] if r["with_sparse"]]
+
+    async def go():
+        return await asyncio.gather(*[retr.retrieve(f"q{r['query']}", profile_hint="default") for r in runs])
+
+    try:
+        outs = asyncio.run(go())
+        for run, out in zip(runs, outs):
+            assert [o["id"] for o in out] == run["ids"], run["query"]
+            assert [float(o["score"]).hex() for o in out] == run["scores"]
+            assert [sorted(o["retrieval_methods"]) for o in out] == run["methods"]
+        st = mgr._front.stats
+        assert st["requests"] == 3 * len(runs)                    # dense + sparse + fusion per retrieve()
+        assert st["dense_launches"] + st["sparse_launches"] < 2 * len(runs)   # they did share launches
+    finally:
+        asyncio.run(mgr.close())
+
+
+def test_128_concurrent_retrieves_equal_sequential_calls(gpu, long_timeout):
+    from advanced_rag.embedding_cache import initialize_caches
+    rng = np.random.default_rng(3)
+    n, d, V, nq = 50000, 96, 2000, 128
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    X[40000] = X[17]  # a tie
+    idx = np.sort(np.argpartition(rng.random((n, V)), 19, axis=1)[:, :20], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * 20)).astype(np.float32)
+    ptr = np.arange(n + 1, dtype=np.int64) * 20
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q[5] = X[17]
+    SQ = [(np.sort(rng.choice(V, 40, replace=False)).astype(np.int32), np.abs(rng.standard_normal(40)).astype(np.float32))
+          for _ in range(nq)]
+    results = {}
+    for coalesce in (False, True):
+        initialize_caches()
+        mgr = MilvusIndexManager(semantic_dim=d, sparse_dim=V, dtype="float16", enable_domain=False, coalesce=coalesce)
+        mgr.add_rows(X, (ptr, idx, val), chunk_index=(np.arange(n) % 10).tolist())
+        mgr.finalize()
+        mgr.embedding_generator = TableGen(Q, SQ)
+        retr = HybridRetriever(mgr, RetrievalConfig(top_k=20))
+
+        async def sequential():
+            return [await retr.retrieve(f"q{i}", profile_hint="default") for i in range(nq)]
+
+        async def concurrent():
+            plain = [retr.retrieve(f"q{i}", profile_hint="default") for i in range(nq)]
+            filtered = [retr.retrieve(f"q{i}", filters={"chunk_index": {"$lt": 5}}, profile_hint="default") for i in range(0, nq, 4)]
+            return await asyncio.gather(*plain, *filtered)
+
+        try:
+            if coalesce:
+                outs = asyncio.run(concurrent())
+                results["concurrent"] = [_strip(o) for o in outs[:nq]]
+                results["filtered"] = [_strip(o) for o in outs[nq:]]
+                st = dict(mgr._front.stats)
+                assert st["dense_launches"] + st["sparse_launches"] <= (2 * (nq + nq // 4)) // 4, st   # >= 4 queries per launch
+                assert st["max_batch_seen"] >= 16, st
+                seq2 = asyncio.run(sequential())          # the front also serves one caller at a time
+                assert [_strip(o) for o in seq2] == results["concurrent"]
+            else:
+                results["sequential"] = [_strip(o) for o in asyncio.run(sequential())]
+
+                async def filtered_seq():
+                    return [await retr.retrieve(f"q{i}", filters={"chunk_index": {"$lt": 5}}, profile_hint="default")
+                            for i in range(0, nq, 4)]
+                results["filtered_sequential"] = [_strip(o) for o in asyncio.run(filtered_seq())]
+        finally:
+            asyncio.run(mgr.close())
+    assert all(len(r) == 20 for r in results["sequential"])
+    assert results["concurrent"] == results["sequential"]
+    assert results["filtered"] == results["filtered_sequential"]
+    assert all(ci < 5 for r in results["filtered"] for (_, _, _, ci) in r)
+
+
+def test_a_bad_request_fails_alone(gpu, long_timeout):
+    """One malformed sparse query (duplicate index) inside a coalesced batch: that search fails (the retriever turns it
+    into "no sparse hits", retrieval.py:387-389), the others are served."""
+    rng = np.random.default_rng(5)
+    n, d, V = 5000, 32, 300
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    idx = np.sort(np.argpartition(rng.random((n, V)), 9, axis=1)[:, :10], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * 10)).astype(np.float32)
+    mgr = MilvusIndexManager(semantic_dim=d, sparse_dim=V, dtype="float16", enable_domain=False)
+    mgr.add_rows(X, (np.arange(n + 1, dtype=np.int64) * 10, idx, val))
+    mgr.finalize()
+    good = {"indices": [1, 5, 9], "values": [1.0, 0.5, 0.25]}
+    bad = {"indices": [1, 1, 9], "values": [1.0, 0.5, 0.25]}
+
+    async def go():
+        calls = [mgr.search(good, "sparse_index", 10) for _ in range(6)] + [mgr.search(bad, "sparse_index", 10)]
+        return await asyncio.gather(*calls, return_exceptions=True)
+
+    try:
+        outs = asyncio.run(go())
+        assert isinstance(outs[-1], Exception)
+        assert all(isinstance(o, list) and len(o) == 10 for o in outs[:-1])
+        assert all([h["id"] for h in o] == [h["id"] for h in outs[0]] for o in outs[:-1])
+    finally:
+        asyncio.run(mgr.close())

@@ -189,3 +189,65 @@ def test_dev_searches_sharing_a_stream_are_serialised(gpu):
         th.join()
     assert not errors, errors
     h.close()
+
+
+def test_device_to_device_ingest_equals_host_ingest(gpu):
+    """index_chunks with an encoder that offers encode_to_device: the dense (and domain) rows go from the encoder's
+    output tensor into the shard without a host hop (hr_add_dense_raw_dev).  The shard must be the one the host path
+    builds — same rows, same fp16 rounding — so searches return identical lists, and both equal the oracle on the
+    encoder's own output."""
+    import asyncio
+    from advanced_rag import AdvancedRAGPipeline, BM25SparseEncoder, PipelineConfig
+    from advanced_rag.embedding_cache import initialize_caches
+    from advanced_rag.encoders import EncoderConfig, SentenceEncoder
+
+    docs = [{"id": f"d{i}", "text": " ".join(f"Sentence {j} of document {i} mentions topic{(i * j) % 11} and item{j % 5}." for j in range(12)),
+             "metadata": {"source": "unit"}} for i in range(40)]
+    bm25 = BM25SparseEncoder(sparse_dim=512).fit(d["text"] for d in docs)
+    enc = SentenceEncoder(EncoderConfig(hidden=64, layers=2, heads=4, intermediate=128), device="cuda:0", sparse_encoder=bm25,
+                          domain_dim=96, batch_size=16)
+
+    class HostHop:
+        encode_semantic = staticmethod(enc.encode_semantic)
+        encode_semantic_batch = staticmethod(enc.encode_semantic_batch)
+        encode_domain = staticmethod(enc.encode_domain)
+        encode_sparse = staticmethod(enc.encode_sparse)
+        encode_sparse_query = staticmethod(enc.encode_sparse_query)
+
+    mgrs, calls = {}, []
+    for name, gen in (("device", enc), ("host", HostHop())):
+        initialize_caches()
+        p = AdvancedRAGPipeline(config=PipelineConfig(enable_audit_logging=False), semantic_dim=64, sparse_dim=512,
+                                domain_dim=96, dtype="float16")
+        p.index_manager.embedding_generator = gen
+        calls = []
+        for part in (docs[:25], docs[25:]):  # two calls: an append behind a flushed batch
+            rep = asyncio.run(p.ingest_documents(part, domain="manuals"))
+            s = rep["indexing_summary"]
+            assert not s["errors"] and s["indexed_semantic"] == s["total_chunks"] == s["indexed_sparse"] == s["indexed_domain"]
+            assert set(s["timing_ms"]) == {"encode", "append", "flush"}
+            calls.append(s["total_chunks"])
+        mgrs[name] = p
+    md, mh = mgrs["device"].index_manager, mgrs["host"].index_manager
+    assert md._cols["id"] == mh._cols["id"] and md.num_rows == mh.num_rows == sum(calls) > 40
+    texts = md._cols["content"]
+    # the encoder's own output for the same call pattern (a forward pass is only bit-reproducible for the same batch
+    # composition): semantic rows are encoded per ingest call on both paths; domain rows per call on the device path
+    # and one text at a time on the host path
+    per_call = [texts[:calls[0]], texts[calls[0]:]]
+    X = np.concatenate([np.stack(enc.encode_semantic_batch(t)) for t in per_call]).astype(np.float16)
+    Xd_dev = np.concatenate([enc.encode_domain_to_device(t, "manuals").cpu().numpy() for t in per_call]).astype(np.float16)
+    Xd_host = np.stack([enc.encode_domain(t, "manuals") for t in texts]).astype(np.float16)
+    rng = np.random.default_rng(2)
+    for coll, refs, dim in (("semantic_index", (X, X), 64), ("domain_index", (Xd_dev, Xd_host), 96)):
+        Q = rng.standard_normal((9, dim)).astype(np.float32)
+        Q[0] = refs[0][3].astype(np.float32)
+        for mgr, ref in zip((md, mh), refs):
+            got = mgr.collections[coll].handle.search_dense(Q, 30)
+            oi, os_ = oracle.dense_search(ref, Q, 30, oracle.COSINE)
+            assert np.array_equal(got[0], oi) and np.array_equal(got[1].view(np.uint32), os_.view(np.uint32)), coll
+    # sparse rows travelled as one CSR per call on both paths
+    sq = [(np.asarray(bm25.encode_query(texts[5])["indices"], np.int32), np.asarray(bm25.encode_query(texts[5])["values"], np.float32))]
+    assert all(np.array_equal(a, b) for a, b in zip(md._main.first.search_sparse(sq, 20, 0.2), mh._main.first.search_sparse(sq, 20, 0.2)))
+    for p in mgrs.values():
+        asyncio.run(p.close())
