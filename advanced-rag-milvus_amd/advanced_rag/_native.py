@@ -62,6 +62,12 @@ _SIGNATURES = {
                                    _c.c_void_p]),
     "hr_search_sparse": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int,
                                     _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_search_dense_dmask": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                         _c.c_void_p]),
+    "hr_search_sparse_dmask": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int,
+                                          _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_filter_eval_dev": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                      _c.c_void_p, _c.c_void_p]),
     "hr_fuse_rrf": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int,
                                _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_void_p,
                                _c.c_void_p, _c.c_void_p]),
@@ -262,19 +268,25 @@ class ShardHandle:
             raise ValueError(f"row mask has {m.size} bytes, the collection's {n_rows} rows need {(n_rows + 7) // 8}")
         return m
 
-    def search_dense(self, q: np.ndarray, k: int, rowmask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+    def search_dense(self, q: np.ndarray, k: int, rowmask: Optional[np.ndarray] = None,
+                     d_rowmask: int = 0) -> Tuple[np.ndarray, np.ndarray]:
+        """rowmask = packed host mask (uploaded), or d_rowmask = device pointer of a mask already in HBM."""
         q = np.ascontiguousarray(np.atleast_2d(q), dtype=np.float32)
         if q.shape[1] != self.dim:
             raise ValueError(f"query dim {q.shape[1]} != shard dim {self.dim}")
         B = q.shape[0]
         ids = np.empty((B, k), dtype=np.int64)
         sc = np.empty((B, k), dtype=np.float32)
+        if d_rowmask:
+            self._check(self._lib.hr_search_dense_dmask(self._h, _vp(q), B, k, _vp(d_rowmask), _vp(ids), _vp(sc)))
+            return ids, sc
         m = self._mask(rowmask, self.num_rows)
         self._check(self._lib.hr_search_dense(self._h, _vp(q), B, k, _vp(m), _vp(ids), _vp(sc)))
         return ids, sc
 
     def search_sparse(self, queries: Sequence[Tuple[Sequence[int], Sequence[float]]], k: int,
-                      drop_ratio: float = 0.0, rowmask: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+                      drop_ratio: float = 0.0, rowmask: Optional[np.ndarray] = None,
+                      d_rowmask: int = 0) -> Tuple[np.ndarray, np.ndarray]:
         B = len(queries)
         indptr = np.zeros(B + 1, dtype=np.int64)
         for b, (qi, _) in enumerate(queries):
@@ -285,6 +297,10 @@ class ShardHandle:
         val = np.ascontiguousarray(val, dtype=np.float32)
         ids = np.empty((B, k), dtype=np.int64)
         sc = np.empty((B, k), dtype=np.float32)
+        if d_rowmask:
+            self._check(self._lib.hr_search_sparse_dmask(self._h, _vp(indptr), _vp(idx), _vp(val), B, k, float(drop_ratio),
+                                                         _vp(d_rowmask), _vp(ids), _vp(sc)))
+            return ids, sc
         m = self._mask(rowmask, self.num_sparse_rows)
         self._check(self._lib.hr_search_sparse(self._h, _vp(indptr), _vp(idx), _vp(val), B, k, float(drop_ratio),
                                                _vp(m), _vp(ids), _vp(sc)))
@@ -393,6 +409,26 @@ def merge_topk_dev(d_scores: int, d_ids: int, n_lists: int, B: int, k_in: int, k
     L = load_library()
     rc = L.hr_merge_topk_dev(_vp(d_scores), _vp(d_ids), n_lists, score_stride or B * k_in, id_stride or B * k_in, B,
                              k_in, k_out, _vp(d_out_ids), _vp(d_out_scores), _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+class FilterTerm(ctypes.Structure):
+    """hr_filter_term of include/hbmrag.h."""
+    _fields_ = [("kind", _c.c_int32), ("op", _c.c_int32), ("col", _c.c_void_p), ("ival", _c.c_int64), ("dval", _c.c_double),
+                ("fval", _c.c_float), ("reserved", _c.c_uint32), ("key", _c.c_uint64 * 2)]
+
+
+HR_COL_I64, HR_COL_I64_VS_F64, HR_COL_F32, HR_COL_STR16 = 0, 1, 2, 3
+FILTER_OPS = {"==": 0, "!=": 1, "<": 2, "<=": 3, ">": 4, ">=": 5}
+
+
+def filter_eval_dev(terms: Sequence["FilterTerm"], n_rows: int, d_deleted: int, d_mask: int, d_undecided: int,
+                    d_counts: int, stream: int = 0):
+    L = load_library()
+    arr = (FilterTerm * max(len(terms), 1))(*terms)
+    rc = L.hr_filter_eval_dev(ctypes.byref(arr), len(terms), n_rows, _vp(d_deleted) if d_deleted else None, _vp(d_mask),
+                              _vp(d_undecided), _vp(d_counts), _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
 

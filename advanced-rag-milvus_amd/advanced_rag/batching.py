@@ -98,7 +98,9 @@ class SearchCoalescer:
     def _run(self):
         import torch
         dev = torch.device("cuda", self.mgr.device)
-        stream = torch.cuda.Stream(dev)
+        # one stream per kind of work: the dense and the sparse searches of a round run side by side (a lone retrieve()
+        # overlaps its two scans, as its two worker threads did before the front existed)
+        streams = {k: torch.cuda.Stream(dev) for k in ("dense", "sparse", "fuse")}
         while True:
             reqs = self._collect()
             if reqs is None:
@@ -109,9 +111,11 @@ class SearchCoalescer:
                 groups.setdefault((r.kind, r.key), []).append(r)
             self.stats["rounds"] += 1
             self.stats["requests"] += len(reqs)
-            launched = []
-            with torch.cuda.stream(stream):
-                for (kind, key), rs in groups.items():
+            launched, used = [], set()
+            for (kind, key), rs in groups.items():
+                stream = streams[kind]
+                used.add(kind)
+                with torch.cuda.stream(stream):
                     for c0 in range(0, len(rs), self.max_batch):
                         chunk = rs[c0:c0 + self.max_batch]
                         self.stats["max_batch_seen"] = max(self.stats["max_batch_seen"], len(chunk))
@@ -119,7 +123,8 @@ class SearchCoalescer:
                             launched.append((kind, key, chunk, getattr(self, "_enqueue_" + kind)(torch, dev, stream, key, chunk)))
                         except Exception as e:   # a bad batch must not take the other groups down: one by one
                             launched.append((kind, key, chunk, e))
-                stream.synchronize()
+            for kind in used:
+                streams[kind].synchronize()
             for kind, key, chunk, state in launched:
                 if isinstance(state, Exception):
                     self._one_by_one(kind, key, chunk)

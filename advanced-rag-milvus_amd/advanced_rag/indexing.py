@@ -34,6 +34,7 @@ from typing import Any, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import filters as _filters
+from .columns import FLOAT_COLUMNS, PayloadColumns
 from .constants import IndexingConstants
 from .embedding_cache import get_semantic_cache
 from .shards import PartialAppend, ShardSet
@@ -121,10 +122,10 @@ class MilvusIndexManager:
                                                      thread_name_prefix="embedding-")
         self._main = None      # ShardSet: semantic + sparse
         self._domain = None    # ShardSet: domain
-        self._cols: Dict[str, list] = {k: [] for k in ("id", "doc_id", "content", "chunk_index", "token_count",
-                                                       "entropy", "redundancy", "domain_density", "timestamp",
-                                                       "metadata_json")}
-        self._np_cols: Optional[Dict[str, np.ndarray]] = None
+        # payload columns keyed by global row: append-only numeric arrays and offset-encoded strings (columns.py); the
+        # filterable ones are mirrored into HBM on first use (device_filters.py)
+        self._cols = PayloadColumns()
+        self._dev_filters = None
         self._deleted: Optional[np.ndarray] = None
         self._mask_cache: Dict[Any, Optional[np.ndarray]] = {}   # (expr, rows, delete epoch) -> boolean row filter
         self._delete_epoch = 0
@@ -201,6 +202,9 @@ class MilvusIndexManager:
             self.collections["sparse_index"] = ShardCollection(self, "sparse_index", "sparse", self._main,
                                                                self.sparse_dim, "IP")
         self._synthetic_rows = int(synthetic_rows)
+        self._dev_filters = None
+        self._dev_masks.clear()
+        self._mask_cache.clear()
 
     def serve(self):
         """Ranks > 0 of the torchrun form: answer rank 0's searches until it calls stop_workers()."""
@@ -211,18 +215,11 @@ class MilvusIndexManager:
 
     # ------------------------------------------------------------------ host columns
     def _columns(self) -> Dict[str, np.ndarray]:
-        if self._np_cols is None:
-            c = self._cols
-            self._np_cols = {
-                "id": np.asarray(c["id"], dtype=str), "chunk_id": np.asarray(c["id"], dtype=str),
-                "doc_id": np.asarray(c["doc_id"], dtype=str), "timestamp": np.asarray(c["timestamp"], dtype=str),
-                "chunk_index": np.asarray(c["chunk_index"], dtype=np.int64),
-                "token_count": np.asarray(c["token_count"], dtype=np.int64),
-                "entropy": np.asarray(c["entropy"], dtype=np.float32),
-                "redundancy": np.asarray(c["redundancy"], dtype=np.float32),
-                "domain_density": np.asarray(c["domain_density"], dtype=np.float32),
-            }
-        return self._np_cols
+        """numpy view of the filterable columns for the HOST restatement of the filter semantics (filters.evaluate): CPU
+        tests and collections without a device; string fields are materialised as unicode arrays here."""
+        if hasattr(self._cols, "filter_columns"):
+            return self._cols.filter_columns()
+        return {k: np.asarray(v) for k, v in self._cols.items()}
 
     @property
     def num_rows(self) -> int:
@@ -233,31 +230,62 @@ class MilvusIndexManager:
         """String id of a bulk-ingested row: doc{row//10}::{row%10}::{row:08x} (SURVEY §8d)."""
         return f"doc{row // 10}::{row % 10}::{row:08x}"
 
-    def _row_mask(self, expr: Optional[str]) -> Optional[np.ndarray]:
-        """Boolean filter over global rows for a filter expression plus the tombstones, or None for "all rows".
-        Evaluating an expression is a pass over every payload row: the result is kept per (expression, row count,
-        tombstone epoch) so that repeated requests with the same filter pay for it once."""
+    def _filters_on_device(self):
+        """The device evaluator of this collection's filter expressions, or None (no GPU shard: CPU-only unit tests)."""
+        main = getattr(self, "_main", None)
+        if main is None or not hasattr(main, "first") or not hasattr(main.first, "_h"):
+            return None
+        if self._dev_filters is None:
+            from .device_filters import DeviceFilters
+            self._dev_filters = DeviceFilters(None if self._synthetic_rows else self._cols, main.first.device)
+        return self._dev_filters
+
+    def _global_device_mask(self, expr: Optional[str]):
+        """Packed mask over GLOBAL rows of `expr` + tombstones as a CUDA tensor (None = all rows), evaluated on the
+        device and kept per (expression, rows, tombstone epoch)."""
         n = self.num_rows
-        if self._synthetic_rows and not expr:
+        dead = self._deleted is not None and bool(self._deleted[:n].any())
+        if not expr and not dead:
+            return None
+        key = ("global", expr, n, self._delete_epoch)
+        hit = self._dev_masks.get(key)
+        if hit is None:
+            if len(self._dev_masks) >= 32:
+                self._dev_masks.pop(next(iter(self._dev_masks)))
+            hit = self._dev_masks[key] = self._filters_on_device().evaluate(expr, n, self._deleted if dead else None)[0]
+        return hit
+
+    def _row_mask(self, expr: Optional[str]) -> Optional[np.ndarray]:
+        """Boolean filter over global rows for a filter expression plus the tombstones, or None for "all rows" — the
+        host-side view of the mask (sharded / collective searches cut it up per shard).  With a GPU shard the
+        predicate is evaluated on the device and read back once; without one (CPU-only tests) filters.evaluate runs on
+        the host columns.  Kept per (expression, row count, tombstone epoch)."""
+        n = self.num_rows
+        if self._synthetic_rows and not expr and not (self._deleted is not None and self._deleted[:n].any()):
             return None
         key = (expr, n, self._delete_epoch)
         if key in self._mask_cache:
             return self._mask_cache[key]
         keep = None
-        if expr and self._synthetic_rows:
-            # bulk-ingested rows carry no payload columns; what their synthetic id encodes can still be filtered on:
-            # chunk_index = row % 10 (synthetic_id), derived on the fly
-            fields = {f for f, _, _ in _filters.parse(expr)}
-            if fields - {"chunk_index"}:
-                raise ValueError("this shard was bulk-ingested without payload columns: only chunk_index (= row % 10) "
-                                 f"can be filtered on, not {sorted(fields - {'chunk_index'})}")
-            keep = _filters.evaluate(expr, {"chunk_index": np.arange(n, dtype=np.int64) % 10}, n)
-        elif expr:
-            keep = _filters.evaluate(expr, self._columns(), n)
-        if self._deleted is not None and self._deleted[:n].any():
-            alive = np.ones(n, dtype=bool)
-            alive[:self._deleted.shape[0]] = ~self._deleted[:n]
-            keep = alive if keep is None else (keep & alive)
+        if self._filters_on_device() is not None:
+            m = self._global_device_mask(expr)
+            if m is not None:
+                keep = np.unpackbits(m.cpu().numpy(), bitorder="little")[:n].astype(bool)
+        else:
+            if expr and self._synthetic_rows:
+                # bulk-ingested rows carry no payload columns; what their synthetic id encodes can still be filtered on:
+                # chunk_index = row % 10 (synthetic_id), derived on the fly
+                fields = {f for f, _, _ in _filters.parse(expr)}
+                if fields - {"chunk_index"}:
+                    raise ValueError("this shard was bulk-ingested without payload columns: only chunk_index (= row % 10) "
+                                     f"can be filtered on, not {sorted(fields - {'chunk_index'})}")
+                keep = _filters.evaluate(expr, {"chunk_index": np.arange(n, dtype=np.int64) % 10}, n)
+            elif expr:
+                keep = _filters.evaluate(expr, self._columns(), n)
+            if self._deleted is not None and self._deleted[:n].any():
+                alive = np.ones(n, dtype=bool)
+                alive[:self._deleted.shape[0]] = ~self._deleted[:n]
+                keep = alive if keep is None else (keep & alive)
         if len(self._mask_cache) >= 64:
             self._mask_cache.pop(next(iter(self._mask_cache)))
         self._mask_cache[key] = keep
@@ -265,7 +293,11 @@ class MilvusIndexManager:
 
     def _tombstone(self, expr: str):
         n = self.num_rows
-        hit = _filters.evaluate(expr, self._columns(), n)
+        dev = self._filters_on_device()
+        if dev is not None:
+            hit = np.unpackbits(dev.evaluate(expr, n)[0].cpu().numpy(), bitorder="little")[:n].astype(bool)
+        else:
+            hit = _filters.evaluate(expr, self._columns(), n)
         if self._deleted is None or self._deleted.shape[0] < n:
             grown = np.zeros(n, dtype=bool)
             if self._deleted is not None:
@@ -406,19 +438,16 @@ class MilvusIndexManager:
 
     def _append_payload(self, chunks):
         c = self._cols
-        for chunk in chunks:
-            m = chunk.metadata
-            c["id"].append(m.chunk_id)
-            c["doc_id"].append(str(m.doc_id))
-            c["content"].append(chunk.text[:65535])
-            c["chunk_index"].append(int(m.chunk_index))
-            c["token_count"].append(int(m.token_count))
-            c["entropy"].append(_f32(m.entropy))
-            c["redundancy"].append(_f32(m.redundancy))
-            c["domain_density"].append(_f32(m.domain_density))
-            c["timestamp"].append(str(m.timestamp))
-            c["metadata_json"].append(str(m.to_dict())[:10000])
-        self._np_cols = None
+        metas = [ch.metadata for ch in chunks]
+        c["id"].extend(m.chunk_id for m in metas)
+        c["doc_id"].extend(str(m.doc_id) for m in metas)
+        c["content"].extend(ch.text[:65535] for ch in chunks)
+        c["chunk_index"].extend([int(m.chunk_index) for m in metas])
+        c["token_count"].extend([int(m.token_count) for m in metas])
+        for name in FLOAT_COLUMNS:   # FLOAT fields hold float32 (reference schema, indexing.py:200-202)
+            c[name].extend([getattr(m, name) for m in metas])
+        c["timestamp"].extend(str(m.timestamp) for m in metas)
+        c["metadata_json"].extend(str(m.to_dict())[:10000] for m in metas)
         self._mask_cache.clear()
         self._dev_masks.clear()
 
@@ -432,17 +461,17 @@ class MilvusIndexManager:
         base = self.num_rows
         _, _, sparse_err = self._main.add(dense, sparse_csr if "sparse_index" in self.collections else None)
         c = self._cols
-        c["id"].extend(ids if ids is not None else [f"doc{(base + r) // 10}::{(base + r) % 10}::{base + r:08x}"
-                                                    for r in range(n)])
-        c["content"].extend(contents if contents is not None else [""] * n)
-        defaults = {"doc_id": lambda r: f"doc{(base + r) // 10}", "chunk_index": lambda r: (base + r) % 10,
-                    "token_count": lambda r: 0, "entropy": lambda r: 0.0, "redundancy": lambda r: 0.0,
-                    "domain_density": lambda r: 0.0, "timestamp": lambda r: "", "metadata_json": lambda r: ""}
-        for name, fn in defaults.items():
-            given = scalar_columns.get(name)
-            vals = list(given) if given is not None else [fn(r) for r in range(n)]
-            c[name].extend([_f32(v) for v in vals] if name in _FLOAT_FIELDS else vals)
-        self._np_cols = None
+        defaults = {"doc_id": lambda r: f"doc{r // 10}", "chunk_index": lambda r: r % 10, "token_count": lambda r: 0,
+                    "entropy": lambda r: 0.0, "redundancy": lambda r: 0.0, "domain_density": lambda r: 0.0,
+                    "timestamp": lambda r: "", "metadata_json": lambda r: ""}
+        step = 1 << 18   # bounded temporaries: the columns hold bytes and numbers, not Python objects
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            c["id"].extend(ids[lo:hi] if ids is not None else (self.synthetic_id(base + r) for r in range(lo, hi)))
+            c["content"].extend(contents[lo:hi] if contents is not None else ("" for _ in range(lo, hi)))
+            for name, fn in defaults.items():
+                given = scalar_columns.get(name)
+                c[name].extend(given[lo:hi] if given is not None else [fn(base + r) for r in range(lo, hi)])
         self._mask_cache.clear()
         self._dev_masks.clear()
         if sparse_err is not None:  # the rows are in (with empty sparse rows); the caller still hears about it
@@ -451,10 +480,13 @@ class MilvusIndexManager:
     def add_rows_synthetic(self, dense: np.ndarray, sparse_csr=None):
         """Bulk ingest without host payload columns: ids/metadata are derived from the row
         number on demand (10M-row benchmarks would otherwise hold GBs of Python strings)."""
-        if self._cols["id"]:
+        if len(self._cols["id"]):
             raise ValueError("shard already holds payload columns")
         _, _, sparse_err = self._main.add(dense, sparse_csr if "sparse_index" in self.collections else None)
         self._synthetic_rows += dense.shape[0]
+        self._dev_filters = None
+        self._dev_masks.clear()
+        self._mask_cache.clear()
         if sparse_err is not None:
             raise sparse_err
 
@@ -470,8 +502,7 @@ class MilvusIndexManager:
         self._main.save(lambda s: os.path.join(directory, f"main.{s}.hbmrag"))
         if self._domain is not None:
             self._domain.save(lambda s: os.path.join(directory, f"domain.{s}.hbmrag"))
-        cols = {k: np.asarray(v, dtype=str if k in ("id", "doc_id", "content", "timestamp", "metadata_json") else None)
-                for k, v in self._cols.items()}
+        cols = {k: (v.as_str_array() if hasattr(v, "as_str_array") else v.array()) for k, v in self._cols.items()}
         deleted = self._deleted if self._deleted is not None else np.zeros(0, dtype=bool)
         maps = {f"rows_main_{s}": r for s, r in enumerate(self._main.row_maps())}
         if self._domain is not None:
@@ -499,9 +530,10 @@ class MilvusIndexManager:
                 self._domain.adopt(dom, [z[f"rows_domain_{s}"] for s in range(n_shards)])
             self._synthetic_rows = int(z["synthetic_rows"])
             self._deleted = z["deleted"].copy() if z["deleted"].size else None
+            self._cols = PayloadColumns()
             for k in self._cols:
-                self._cols[k] = z[f"col_{k}"].tolist()
-        self._np_cols = None
+                self._cols[k].extend(z[f"col_{k}"].tolist())
+        self._dev_filters = None
         self._mask_cache.clear()
         self._dev_masks.clear()
 
@@ -569,12 +601,24 @@ class MilvusIndexManager:
     def _search_lists_blocking(self, query, collection_name: str, top_k: int, filters: Optional[str], params: Dict):
         """(row ids [k], scores [k]) of ONE query through the host forms (which escalate until the list is proven)."""
         coll = self.collections[collection_name]
+        drop = float((params.get("params") or params).get("drop_ratio_search", 0.0))
+        if getattr(coll.handle, "n_shards", 1) == 1 and hasattr(coll.handle, "handles") and self._filters_on_device() is not None:
+            # one local GPU shard: the mask never leaves the device
+            h = coll.handle.first
+            d_mask = self._device_row_mask(filters, coll.kind)
+            ptr = d_mask.data_ptr() if d_mask is not None else 0
+            if coll.kind == "sparse":
+                ids, sc = h.search_sparse([query], top_k, drop, None, ptr)
+            elif hasattr(query, "is_cuda") and query.is_cuda and d_mask is None:
+                ids, sc = self._search_dense_device(h, query, top_k)
+            else:
+                if hasattr(query, "detach"):
+                    query = query.detach().cpu().numpy()
+                ids, sc = h.search_dense(np.asarray(query, dtype=np.float32).reshape(1, -1), top_k, None, ptr)
+            return ids[0], sc[0]
         mask = self._row_mask(filters)
         if coll.kind == "sparse":
-            drop = float((params.get("params") or params).get("drop_ratio_search", 0.0))
             ids, sc = coll.handle.search_sparse([query], top_k, drop, mask)
-        elif hasattr(query, "is_cuda") and query.is_cuda and mask is None and coll.handle.n_shards == 1:
-            ids, sc = self._search_dense_device(coll.handle.first, query, top_k)
         else:
             if hasattr(query, "detach"):
                 query = query.detach().cpu().numpy()
@@ -616,24 +660,16 @@ class MilvusIndexManager:
         return self._front
 
     def _device_row_mask(self, expr: Optional[str], kind: str):
-        """Packed row mask of a filter expression (+ tombstones) as a uint8 CUDA tensor, kept per (expression, rows,
-        tombstone epoch): a batch of filtered searches uploads nothing.  None = all rows."""
-        keep = self._row_mask(expr)
-        if keep is None:
+        """Packed row mask of a filter expression (+ tombstones) for a single-shard collection, as a uint8 CUDA tensor
+        evaluated on the device (device_filters.py) and kept per (expression, rows, tombstone epoch): a batch of filtered
+        searches uploads nothing.  None = all rows."""
+        g = self._global_device_mask(expr)
+        if g is None:
             return None
-        key = (expr, self.num_rows, self._delete_epoch, kind)
-        hit = self._dev_masks.get(key)
-        if hit is None:
-            import torch
-            n_local = self._main.first.num_sparse_rows if kind == "sparse" else self._main.first.num_rows
-            packed = np.packbits(keep, bitorder="little")
-            need = (n_local + 7) // 8
-            if packed.size < need:
-                raise ValueError(f"row mask has {packed.size} bytes, the collection's {n_local} rows need {need}")
-            if len(self._dev_masks) >= 16:
-                self._dev_masks.pop(next(iter(self._dev_masks)))
-            hit = self._dev_masks[key] = torch.from_numpy(packed).to(f"cuda:{self.device}")
-        return hit
+        n_local = self._main.first.num_sparse_rows if kind == "sparse" else self._main.first.num_rows
+        if g.numel() * 8 < n_local:
+            raise ValueError(f"row mask covers {g.numel() * 8} rows, the collection holds {n_local}")
+        return g
 
     @staticmethod
     def _params_key(params: Dict) -> tuple:

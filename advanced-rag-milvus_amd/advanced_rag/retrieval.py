@@ -283,7 +283,7 @@ class HybridRetriever:
             hit["score"] = score
             hit["retrieval_methods"] = [m for i, m in enumerate(_METHOD_ORDER) if i in seen_in]
             meta = hit.get("metadata")
-            if isinstance(meta, dict) and "timestamp" in meta and "recency" not in meta:
+            if isinstance(meta, dict) and meta.get("timestamp") and "recency" not in meta:   # "" never parses: no recency
                 try:
                     age_days = max(0.0, (now - datetime.fromisoformat(str(meta["timestamp"]))).total_seconds() / 86400.0)
                     meta["recency"] = float(1.0 / (1.0 + age_days))

@@ -54,6 +54,7 @@ class ShardSet:
         self.handles = list(handles)
         self.rows_of: List[np.ndarray] = [np.zeros(0, np.int64) for _ in handles]  # global row of each local row
         self._n = 0
+        self._packed = None   # (filter array, {shard: packed mask}) of the filter used last
         self._pool = ThreadPoolExecutor(max_workers=len(handles), thread_name_prefix="shard-") if len(handles) > 1 else None
 
     # ------------------------------------------------------------------ shape
@@ -166,12 +167,29 @@ class ShardSet:
             self._pool = None
 
     # ------------------------------------------------------------------ search
-    def _local_mask(self, s: int, keep: Optional[np.ndarray]) -> Optional[np.ndarray]:
+    def _local_mask(self, s: int, keep: Optional[np.ndarray]):
+        """Shard s's packed row mask of a boolean filter over GLOBAL rows -> positional arguments (rowmask, d_rowmask)
+        of the handle's search.  Cut out and packed ONCE per filter (the manager hands the same array object for the
+        same expression) and, for real shard handles, uploaded once: later searches with that filter pass a device
+        pointer — no gather over the rows and no N/8-byte upload per search."""
         if keep is None:
-            return None
-        if self.n_shards == 1 and len(self.rows_of[0]) == len(keep):
-            return np.packbits(keep, bitorder="little")
-        return np.packbits(keep[self.rows_of[s]], bitorder="little")
+            return ()
+        ent = self._packed
+        if ent is None or ent[0] is not keep:
+            self._packed = ent = (keep, {})
+        hit = ent[1].get(s)
+        if hit is None:
+            own = keep if (self.n_shards == 1 and len(self.rows_of[0]) == len(keep)) else keep[self.rows_of[s]]
+            packed = np.packbits(own, bitorder="little")
+            h = self.handles[s]
+            if getattr(h, "_h", None) is not None:   # a libhbmrag shard: keep the mask in its HBM
+                import torch
+                hit = (None, torch.from_numpy(packed).to(f"cuda:{h.device}"))
+            else:
+                hit = (packed, None)
+            ent[1][s] = hit
+        packed, dev = hit
+        return (packed,) if dev is None else (None, dev.data_ptr())
 
     def _fan_out(self, fn):
         if self._pool is None:
@@ -194,14 +212,14 @@ class ShardSet:
             if self.handles[s].num_rows == 0:
                 B = np.atleast_2d(q).shape[0]
                 return np.full((B, k), -1, np.int64), np.zeros((B, k), np.float32)
-            return self.handles[s].search_dense(q, k, self._local_mask(s, keep))
+            return self.handles[s].search_dense(q, k, *self._local_mask(s, keep))
         return self._gather(self._fan_out(one), k)
 
     def search_sparse(self, queries, k: int, drop_ratio: float = 0.0, keep: Optional[np.ndarray] = None):
         def one(s):
             if self.handles[s].num_sparse_rows == 0:
                 return np.full((len(queries), k), -1, np.int64), np.zeros((len(queries), k), np.float32)
-            return self.handles[s].search_sparse(queries, k, drop_ratio, self._local_mask(s, keep))
+            return self.handles[s].search_sparse(queries, k, drop_ratio, *self._local_mask(s, keep))
         return self._gather(self._fan_out(one), k)
 
     # ------------------------------------------------------------------ snapshot

@@ -48,17 +48,17 @@ __device__ inline void rrf_fuse_block(
     // a entries own themselves (ids inside one list are unique: one hit per row)
     for (int i = tid; i < na; i += 256) owner[i] = -1;
     for (int i = tid; i < nb; i += 256) {
-        int o = -1;
+        int o = na;   // first a entry with this id (ids inside a list are unique); no early exit: the reads are independent
         const int64_t me = id[na + i];
-        for (int j = 0; j < na; ++j) if (id[j] == me) { o = j; break; }
-        owner[na + i] = o;
+        for (int j = 0; j < na; ++j) o = (id[j] == me && j < o) ? j : o;
+        owner[na + i] = o < na ? o : -1;
     }
     __syncthreads();
     for (int i = tid; i < nc; i += 256) {
-        int o = -1;
+        int first = na + nb;   // first a/b entry with this id
         const int64_t me = id[na + nb + i];
-        for (int j = 0; j < na + nb; ++j) if (id[j] == me) { o = (owner[j] >= 0) ? owner[j] : j; break; }
-        owner[na + nb + i] = o;
+        for (int j = 0; j < na + nb; ++j) first = (id[j] == me && j < first) ? j : first;
+        owner[na + nb + i] = first < na + nb ? ((owner[first] >= 0) ? owner[first] : first) : -1;
     }
     __syncthreads();
     // insertion slots: a -> 0..na-1; new b ids follow in b order; new c ids after them.
@@ -91,7 +91,7 @@ __device__ inline void rrf_fuse_block(
             // contribution from list b: own entry, or the b entry that points here
             int r = -1;
             if (e >= na) r = e - na;
-            else for (int j = 0; j < nb; ++j) if (owner[na + j] == e) { r = j; break; }
+            else for (int j = nb - 1; j >= 0; --j) r = (owner[na + j] == e) ? j : r;   // the b entry that points here (at most one)
             if (r >= 0) {
                 s = __dadd_rn(s, __dmul_rn(1.0 / (double)(rrf_k + r + 1), wb));
                 m |= HR_METHOD_SPARSE;
@@ -100,7 +100,7 @@ __device__ inline void rrf_fuse_block(
         {
             int r = -1;
             if (e >= na + nb) r = e - na - nb;
-            else for (int j = 0; j < nc; ++j) if (owner[na + nb + j] == e) { r = j; break; }
+            else for (int j = nc - 1; j >= 0; --j) r = (owner[na + nb + j] == e) ? j : r;
             if (r >= 0) {
                 s = __dadd_rn(s, __dmul_rn(1.0 / (double)(rrf_k + r + 1), wc));
                 m |= HR_METHOD_DOMAIN;
@@ -149,11 +149,12 @@ __global__ __launch_bounds__(256) void rrf_fuse_kernel(
 // Cross-shard merge of one query: n_lists per-shard lists of k_in (score, id) pairs, each SORTED by score
 // descending (what the top-k kernels write; ids < 0 pad the tail) -> the best k_out by (score desc, id asc).
 // The lists are staged in LDS (s_id / s_sc: n_lists * k_in entries, s_len: n_lists words) and every entry computes its
-// rank in the merged order from two binary searches per list (entries with a larger score; entries with the same
-// score, which are then compared one by one: id ascending, and — for exact duplicates, which only a caller that feeds
-// the same list twice produces — list number, then position, so that ranks are always a permutation).
-// n_lists * k_in * (2 log2 k_in) LDS reads instead of the (n_lists * k_in)^2 global reads of the first form of this
-// kernel: 8 lists of k' = 40 cost ~4k reads per query against 100k, 8 x 200 ~ 25k against 2.5M.
+// rank in the merged order from two counts per list (entries with a larger score; entries with the same score, which
+// are then compared one by one: id ascending, and — for exact duplicates, which only a caller that feeds the same list
+// twice produces — list number, then position, so that ranks are always a permutation).  The counts come from
+// ~2 sqrt(k_in) independent LDS reads per list (splitters, then one stride) instead of the (n_lists * k_in)^2 global
+// reads of the first form of this kernel: 8 lists of k' = 40 cost ~30k LDS reads per query against 100k global ones,
+// 8 x 200 ~ 370k against 2.5M, and none of them waits for another.
 __device__ inline void merge_runs_block(int q, const float* __restrict__ scores, const int64_t* __restrict__ ids,
                                         int n_lists, int64_t score_stride, int64_t id_stride, int k_in, int k_out,
                                         int64_t* __restrict__ out_ids, float* __restrict__ out_scores,
@@ -173,6 +174,8 @@ __device__ inline void merge_runs_block(int q, const float* __restrict__ scores,
     __syncthreads();
     int total = 0;
     for (int r = 0; r < n_lists; ++r) total += s_len[r];
+    int stride = 1;
+    while (stride * stride < k_in) ++stride;   // ~sqrt(k_in): splitters + one stride of entries per list
     for (int e = tid; e < n; e += nt) {
         const int r = e / k_in, p = e - r * k_in;
         if (p >= s_len[r]) continue;
@@ -183,19 +186,20 @@ __device__ inline void merge_runs_block(int q, const float* __restrict__ scores,
             const float* sc = s_sc + r2 * k_in;
             const int64_t* id = s_id + r2 * k_in;
             const int len = s_len[r2];
-            int lo = 0, hi = len;      // first position whose score is <= s
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (sc[mid] > s) lo = mid + 1; else hi = mid;
+            // entries of list r2 with a larger score (gt) and with a score at least as large (ge): two levels of
+            // INDEPENDENT LDS reads — every stride-th entry, then the entries of one stride — instead of the dependent
+            // steps of a binary search: the lists are sorted by score, so the splitters bracket both boundaries
+            int b_gt = 0, b_ge = 0;   // splitters (entries stride-1, 2*stride-1, ...) that are > s / >= s
+            for (int t = stride - 1; t < len; t += stride) {
+                const float v = sc[t];
+                b_gt += v > s;
+                b_ge += v >= s;
             }
-            int eq = lo;
-            hi = len;                  // first position whose score is < s
-            while (eq < hi) {
-                const int mid = (eq + hi) >> 1;
-                if (sc[mid] >= s) eq = mid + 1; else hi = mid;
-            }
-            rank += lo;
-            for (int t = lo; t < eq; ++t) {
+            int gt = b_gt * stride, ge = b_ge * stride;
+            for (int t = b_gt * stride, e2 = min(len, (b_gt + 1) * stride); t < e2; ++t) gt += sc[t] > s;
+            for (int t = b_ge * stride, e2 = min(len, (b_ge + 1) * stride); t < e2; ++t) ge += sc[t] >= s;
+            rank += gt;
+            for (int t = gt; t < ge; ++t) {   // equal scores: id ascending, then list, then position
                 const int64_t u = id[t];
                 rank += (u < i) || (u == i && (r2 < r || (r2 == r && t < p)));
             }

@@ -24,6 +24,7 @@
 #include "common.h"
 #include "dense.h"
 #include "encoder_ops.h"
+#include "filter.h"
 #include "finish.h"
 #include "fuse.h"
 #include "select.h"
@@ -1703,6 +1704,35 @@ int hr_post_lists_dev(const hr_post_args* a, int B, void* stream) {
     return HR_OK;
 }
 
+int hr_filter_eval_dev(const hr_filter_term* terms, int n_terms, int64_t n_rows, const uint8_t* d_deleted, uint8_t* d_mask,
+                       uint8_t* d_undecided, int32_t* d_counts, void* stream) {
+    if (n_terms < 0 || n_terms > kFilterMaxTerms) return fail(nullptr, HR_ELIMIT, "a filter expression may hold up to %d terms", kFilterMaxTerms);
+    if (n_rows < 0 || (n_terms > 0 && !terms) || !d_mask || !d_undecided || !d_counts) return fail(nullptr, HR_EINVAL, "bad filter arguments");
+    if (((uintptr_t)d_mask | (uintptr_t)d_undecided) & 7) return fail(nullptr, HR_EINVAL, "mask buffers must be 8-byte aligned");
+    FilterArgs a{};
+    for (int i = 0; i < n_terms; ++i) {
+        if (terms[i].kind < HR_COL_I64 || terms[i].kind > HR_COL_STR16 || terms[i].op < HR_OP_EQ || terms[i].op > HR_OP_GE || !terms[i].col)
+            return fail(nullptr, HR_EINVAL, "bad filter term %d", i);
+        a.t[i] = terms[i];
+    }
+    a.n_terms = n_terms;
+    a.n_rows = n_rows;
+    a.deleted = d_deleted;
+    a.mask = (unsigned long long*)d_mask;
+    a.undecided = (unsigned long long*)d_undecided;
+    a.counts = d_counts;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(d_counts, 0, 8, s);
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    if (n_rows == 0) return HR_OK;
+    const int64_t n_words = (n_rows + 63) / 64;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_words + 3) / 4, 4096));
+    hipLaunchKernelGGL(filter_eval_kernel, dim3(blocks), dim3(256), 0, s, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "filter_eval_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
 int hr_stream_create(int device, int priority, const uint32_t* cu_mask, int n_words, void** out_stream) {
     if (!out_stream || n_words < 0 || (n_words > 0 && !cu_mask)) return fail(nullptr, HR_EINVAL, "bad stream arguments");
     *out_stream = nullptr;
@@ -1809,8 +1839,8 @@ int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void
 }
 
 // ---- host-buffer, synchronous forms -------------------------------------------------
-int hr_search_dense(hr_index* h, const float* q, int B, int k, const uint8_t* rowmask, int64_t* out_ids,
-                    float* out_scores) {
+static int search_dense_host(hr_index* h, const float* q, int B, int k, const uint8_t* rowmask, bool mask_on_device,
+                             int64_t* out_ids, float* out_scores) {
     HR_TRY(check_search_args(h, B, k, true));
     if (!q || !out_ids || !out_scores) return fail(h, HR_EINVAL, "null buffer");
     std::shared_lock<std::shared_mutex> lk(h->rw);
@@ -1829,8 +1859,8 @@ int hr_search_dense(hr_index* h, const float* q, int B, int k, const uint8_t* ro
     HIP_TRY(h, ws->d_scores.ensure((size_t)B * k * 4));
     HIP_TRY(h, ws->flags.ensure((size_t)B * 4));
     HIP_TRY(h, hipMemcpyAsync(ws->d_q.p, q, (size_t)B * h->dim * 4, hipMemcpyHostToDevice, s));
-    const uint8_t* d_mask = nullptr;
-    if (rowmask) {
+    const uint8_t* d_mask = mask_on_device ? rowmask : nullptr;
+    if (rowmask && !mask_on_device) {
         const size_t mb = (size_t)(h->n_rows + 7) / 8;
         HIP_TRY(h, ws->d_mask.ensure(mb));
         HIP_TRY(h, hipMemcpyAsync(ws->d_mask.p, rowmask, mb, hipMemcpyHostToDevice, s));
@@ -1854,8 +1884,18 @@ int hr_search_dense(hr_index* h, const float* q, int B, int k, const uint8_t* ro
     return HR_OK;
 }
 
-int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val, int B, int k,
-                     float drop_ratio, const uint8_t* rowmask, int64_t* out_ids, float* out_scores) {
+int hr_search_dense(hr_index* h, const float* q, int B, int k, const uint8_t* rowmask, int64_t* out_ids,
+                    float* out_scores) {
+    return search_dense_host(h, q, B, k, rowmask, false, out_ids, out_scores);
+}
+int hr_search_dense_dmask(hr_index* h, const float* q, int B, int k, const uint8_t* d_rowmask, int64_t* out_ids,
+                          float* out_scores) {
+    return search_dense_host(h, q, B, k, d_rowmask, true, out_ids, out_scores);
+}
+
+static int search_sparse_host(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val, int B, int k,
+                              float drop_ratio, const uint8_t* rowmask, bool mask_on_device, int64_t* out_ids,
+                              float* out_scores) {
     HR_TRY(check_search_args(h, B, k, false));
     if (!q_indptr || !out_ids || !out_scores) return fail(h, HR_EINVAL, "null buffer");
     if (!(drop_ratio >= 0.f && drop_ratio < 1.f)) return fail(h, HR_EINVAL, "drop_ratio must be in [0,1)");
@@ -1917,8 +1957,8 @@ int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx,
         HIP_TRY(h, hipMemcpyAsync(ws->d_qidx.p, idx.data(), nnz * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(h, hipMemcpyAsync(ws->d_qval.p, val.data(), nnz * 4, hipMemcpyHostToDevice, s));
     }
-    const uint8_t* d_mask = nullptr;
-    if (rowmask) {
+    const uint8_t* d_mask = mask_on_device ? rowmask : nullptr;
+    if (rowmask && !mask_on_device) {
         const size_t mb = (size_t)(h->n_sparse + 7) / 8;
         HIP_TRY(h, ws->d_mask.ensure(mb));
         HIP_TRY(h, hipMemcpyAsync(ws->d_mask.p, rowmask, mb, hipMemcpyHostToDevice, s));
@@ -1941,6 +1981,15 @@ int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx,
     HIP_TRY(h, hipMemcpyAsync(out_scores, ws->d_scores.p, (size_t)B * k * 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     return HR_OK;
+}
+
+int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val, int B, int k,
+                     float drop_ratio, const uint8_t* rowmask, int64_t* out_ids, float* out_scores) {
+    return search_sparse_host(h, q_indptr, q_idx, q_val, B, k, drop_ratio, rowmask, false, out_ids, out_scores);
+}
+int hr_search_sparse_dmask(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val, int B, int k,
+                           float drop_ratio, const uint8_t* d_rowmask, int64_t* out_ids, float* out_scores) {
+    return search_sparse_host(h, q_indptr, q_idx, q_val, B, k, drop_ratio, d_rowmask, true, out_ids, out_scores);
 }
 
 int hr_fuse_rrf(hr_index* h, const int64_t* ids_a, int na, const int64_t* ids_b, int nb, const int64_t* ids_c, int nc,

@@ -146,6 +146,14 @@ HR_API int hr_search_sparse(hr_index* h, const int64_t* q_indptr, const int32_t*
                      int B, int k, float drop_ratio, const uint8_t* rowmask,
                      int64_t* out_ids, float* out_scores);
 
+/* The same two searches with the row mask already in HBM (hr_filter_eval_dev's output, or a caller's cached mask):
+ * host buffers in and out, escalation included, no mask upload. */
+HR_API int hr_search_dense_dmask(hr_index* h, const float* q, int B, int k, const uint8_t* d_rowmask,
+                          int64_t* out_ids, float* out_scores);
+HR_API int hr_search_sparse_dmask(hr_index* h, const int64_t* q_indptr, const int32_t* q_idx, const float* q_val,
+                           int B, int k, float drop_ratio, const uint8_t* d_rowmask,
+                           int64_t* out_ids, float* out_scores);
+
 /* Reciprocal-rank fusion of up to three ranked id lists of ONE query
  * (reference HybridRetriever._fuse_results, retrieval.py:421-491), executed
  * by the device kernel.  ids < 0 end a list.  out arrays hold na+nb+nc
@@ -271,6 +279,32 @@ typedef struct hr_post_args {
     int32_t* agg_flags;
 } hr_post_args;
 HR_API int hr_post_lists_dev(const hr_post_args* args, int B, void* stream);
+
+/* ---- filter expressions -> row mask, on the device ------------------------------------------------------------
+ * Replaces the server-side evaluation of the `expr` argument of Collection.search (reference indexing.py:503-525; the
+ * expressions come from HybridRetriever._build_filter_expression, retrieval.py:565-632: a conjunction of
+ * `field OP literal` terms over the scalar fields of the schema, indexing.py:191-225).  Columns are device arrays of
+ * n_rows entries: int64, float32, or — for string fields — two uint64 per row holding the big-endian words of the
+ * first 16 UTF-8 bytes, zero padded (an order-preserving prefix key).  d_mask receives the packed predicate (bit r%8 of
+ * byte r/8, what every search entry point takes as rowmask); rows a string term cannot decide from the key alone
+ * (first 16 bytes equal to the literal's) are left 0 in d_mask and set in d_undecided for the caller to resolve on the
+ * full strings.  Both buffers hold 8 * ceil(n_rows / 64) bytes.  d_counts[2] (zeroed by the call) receives the
+ * number of rows kept / undecided.  d_deleted (optional) = tombstones, 1 bit per row, 1 = never passes. */
+enum { HR_COL_I64 = 0, HR_COL_I64_VS_F64 = 1, HR_COL_F32 = 2, HR_COL_STR16 = 3 };
+enum { HR_OP_EQ = 0, HR_OP_NE = 1, HR_OP_LT = 2, HR_OP_LE = 3, HR_OP_GT = 4, HR_OP_GE = 5 };
+#define HR_MAX_FILTER_TERMS 16
+typedef struct hr_filter_term {
+    int32_t kind;        /* HR_COL_* */
+    int32_t op;          /* HR_OP_*  */
+    const void* col;     /* device column */
+    int64_t ival;        /* literal for HR_COL_I64 */
+    double dval;         /* literal for HR_COL_I64_VS_F64 */
+    float fval;          /* literal for HR_COL_F32 (already rounded to float32) */
+    uint32_t reserved;
+    uint64_t key[2];     /* literal's prefix key for HR_COL_STR16 */
+} hr_filter_term;
+HR_API int hr_filter_eval_dev(const hr_filter_term* terms, int n_terms, int64_t n_rows, const uint8_t* d_deleted,
+                       uint8_t* d_mask, uint8_t* d_undecided, int32_t* d_counts, void* stream);
 
 /* ---- encoder / cross-encoder forward: fused elementwise pieces -----------------
  * The GEMMs and the attention of the PyTorch-ROCm encoder forwards stay with

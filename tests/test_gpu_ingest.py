@@ -229,7 +229,7 @@ def test_device_to_device_ingest_equals_host_ingest(gpu):
             calls.append(s["total_chunks"])
         mgrs[name] = p
     md, mh = mgrs["device"].index_manager, mgrs["host"].index_manager
-    assert md._cols["id"] == mh._cols["id"] and md.num_rows == mh.num_rows == sum(calls) > 40
+    assert md._cols["id"] == mh._cols["id"] and md.num_rows == mh.num_rows == sum(calls) >= 40
     texts = md._cols["content"]
     # the encoder's own output for the same call pattern (a forward pass is only bit-reproducible for the same batch
     # composition): semantic rows are encoded per ingest call on both paths; domain rows per call on the device path

@@ -519,3 +519,45 @@ def test_synthetic_payload_shards_filter_on_what_the_row_number_encodes():
     assert m._row_mask(None) is None
     with pytest.raises(ValueError, match="chunk_index"):
         m._row_mask('doc_id == "doc1"')
+
+
+def test_payload_columns_are_append_only_arrays_not_python_objects():
+    """columns.PayloadColumns (the manager's host payload store): ids / doc ids as offset-encoded UTF-8, numeric fields
+    as numpy arrays; two million rows cost well under 400 MB (10M rows < 2 GB) and an append costs O(batch); the
+    16-byte prefix keys order rows like their strings wherever the prefixes differ."""
+    import time
+    from advanced_rag.columns import PayloadColumns, StringColumn
+    c = PayloadColumns()
+    n, step = 2_000_000, 250_000
+    costs = []
+    for lo in range(0, n, step):
+        t0 = time.perf_counter()
+        c["id"].extend(f"doc{r // 10}::{r % 10}::{r:08x}" for r in range(lo, lo + step))
+        c["doc_id"].extend(f"doc{r // 10}" for r in range(lo, lo + step))
+        c["content"].extend("" for _ in range(step))
+        c["timestamp"].extend("" for _ in range(step))
+        c["metadata_json"].extend("" for _ in range(step))
+        c["chunk_index"].extend(np.arange(lo, lo + step) % 10)
+        c["token_count"].extend(np.zeros(step, np.int64))
+        for k in ("entropy", "redundancy", "domain_density"):
+            c[k].extend(np.zeros(step, np.float32))
+        costs.append(time.perf_counter() - t0)
+    assert c.n_rows == n and c.nbytes < 400e6, c.nbytes
+    assert costs[-1] < 3 * costs[0] + 0.05                  # no rebuild of what is already there
+    assert c["id"][1234567] == "doc123456::7::0012d687" and c["doc_id"][-1] == f"doc{(n - 1) // 10}"
+    assert c["chunk_id"] is c["id"] and c["chunk_index"][13] == 3 and isinstance(c["entropy"][0], float)
+    s = StringColumn()
+    vals = ["b", "a", "", "aé", "0123456789abcdefX", "0123456789abcdefA", "zz", "a" * 40, "a\x00"]
+    s.extend(vals)
+    k = s.keys()
+    for i in range(len(vals)):
+        for j in range(len(vals)):
+            ki, kj = (int(k[i, 0]), int(k[i, 1])), (int(k[j, 0]), int(k[j, 1]))
+            bi, bj = vals[i].encode(), vals[j].encode()
+            if ki != kj:
+                assert (ki < kj) == (bi < bj), (vals[i], vals[j])
+            else:
+                assert bi[:16].ljust(16, b"\x00") == bj[:16].ljust(16, b"\x00")
+    assert s.compare_rows(np.array([4, 5]), "<", "0123456789abcdefB").tolist() == [False, True]
+    s.append("tail")
+    assert s.keys().shape == (len(vals) + 1, 2) and StringColumn.key_of("tail") == (int(s.keys()[-1, 0]), int(s.keys()[-1, 1]))
