@@ -101,6 +101,8 @@ _SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "hr_add_layernorm_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                             _c.c_int, _c.c_float, _c.c_void_p]),
+    "hr_attention_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                        _c.c_float, _c.c_void_p]),
     "hr_set_profiling": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "hr_last_kernel_ms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int]),
 }
@@ -497,6 +499,16 @@ def add_layernorm_f16_dev(d_x: int, d_residual: int, d_gamma: int, d_beta: int, 
     L = load_library()
     rc = L.hr_add_layernorm_f16_dev(_vp(d_x), _vp(d_residual) if d_residual else None, _vp(d_gamma), _vp(d_beta),
                                     _vp(d_out), rows, hidden, eps, _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def attention_f16_dev(d_qkv: int, d_lengths: int, d_out: int, n_seq: int, T: int, heads: int, head_dim: int, scale: float,
+                      stream: int = 0):
+    """softmax(scale Q K^T) V per head from a fused [n_seq, T, 3, heads, head_dim] fp16 QKV buffer into [n_seq, T, H]."""
+    L = load_library()
+    rc = L.hr_attention_f16_dev(_vp(d_qkv), _vp(d_lengths) if d_lengths else None, _vp(d_out), n_seq, T, heads, head_dim,
+                                float(scale), _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
 

@@ -47,6 +47,12 @@ class EncoderConfig:
     max_len: int = 512
     type_vocab: int = 2
     eps: float = 1e-12
+    # FFN activation: "tanh" = GELU's tanh approximation, computed in the epilogue of the up-projection GEMM on the GPU
+    # (hipBLASLt bias + GELU epilogue through torch._addmm_activation: the [tokens, 4H] intermediate is written once
+    # instead of written, re-read and re-written); "erf" = the exact form BERT checkpoints were trained with, as a
+    # separate elementwise pass.  Random-init models (all there is offline) default to the fused form; a caller that
+    # loads real weights with load_local() passes EncoderConfig(gelu="erf") if the last 1e-3 of the logits matters.
+    gelu: str = "tanh"
 
 
 class HashTokenizer:
@@ -102,6 +108,7 @@ class _Layer(nn.Module):
     def __init__(self, c: EncoderConfig):
         super().__init__()
         self.heads = c.heads
+        self.gelu = c.gelu
         self.qkv = nn.Linear(c.hidden, 3 * c.hidden)
         self.out = nn.Linear(c.hidden, c.hidden)
         self.ln1 = nn.LayerNorm(c.hidden, eps=c.eps)
@@ -109,12 +116,30 @@ class _Layer(nn.Module):
         self.down = nn.Linear(c.intermediate, c.hidden)
         self.ln2 = nn.LayerNorm(c.hidden, eps=c.eps)
 
-    def forward(self, x, attn_bias):
+    def forward(self, x, attn_bias, lengths=None):
         B, T, H = x.shape
-        q, k, v = self.qkv(x).view(B, T, 3, self.heads, H // self.heads).permute(2, 0, 3, 1, 4)
-        a = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias)
-        x = add_layer_norm(x, self.out(a.transpose(1, 2).reshape(B, T, H)), self.ln1)  # post-LN, as BERT
-        return add_layer_norm(x, self.down(F.gelu(self.up(x))), self.ln2)
+        hd = H // self.heads
+        qkv = self.qkv(x)
+        if lengths is not None and x.is_cuda and x.dtype == torch.float16 and hd == 32:
+            # head dimension 32 on the GPU: the HIP attention kernel reads the fused projection as it stands and writes
+            # the [tokens, hidden] layout the output projection wants — no permute / transpose copies, no SDPA
+            qkv = qkv.contiguous()
+            a = torch.empty((B, T, H), dtype=x.dtype, device=x.device)
+            _native.attention_f16_dev(qkv.data_ptr(), lengths.data_ptr(), a.data_ptr(), B, T, self.heads, hd, hd ** -0.5,
+                                      torch.cuda.current_stream(x.device).cuda_stream)
+        else:
+            q, k, v = qkv.view(B, T, 3, self.heads, hd).permute(2, 0, 3, 1, 4)
+            a = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_bias).transpose(1, 2).reshape(B, T, H)
+        x = add_layer_norm(x, self.out(a), self.ln1)  # post-LN, as BERT
+        return add_layer_norm(x, self.down(self._ffn_up(x)), self.ln2)
+
+    def _ffn_up(self, x):
+        if self.gelu != "tanh":
+            return F.gelu(self.up(x))
+        if x.is_cuda:   # bias + GELU in the GEMM epilogue
+            B, T, H = x.shape
+            return torch._addmm_activation(self.up.bias, x.reshape(B * T, H), self.up.weight.t(), use_gelu=True).view(B, T, -1)
+        return F.gelu(self.up(x), approximate="tanh")
 
 
 class BertEncoder(nn.Module):
@@ -131,8 +156,11 @@ class BertEncoder(nn.Module):
         T = ids.shape[1]
         x = add_layer_norm(self.word(ids) + self.pos(torch.arange(T, device=ids.device))[None], self.seg(types), self.ln)
         bias = torch.zeros(mask.shape, dtype=x.dtype, device=x.device).masked_fill(~mask, float("-inf"))[:, None, None, :]
+        # valid tokens per sequence for the HIP attention kernel: padding sits at the tail (HashTokenizer.batch), so the
+        # key mask is "position < length"
+        lengths = mask.sum(dim=1).to(torch.int32) if x.is_cuda and x.dtype == torch.float16 else None
         for layer in self.layers:
-            x = layer(x, bias)
+            x = layer(x, bias, lengths)
         return x
 
 

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "attention.h"
 #include "dense.h"
 #include "encoder_ops.h"
 #include "filter.h"
@@ -1835,6 +1836,31 @@ int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void
     else hipLaunchKernelGGL((add_layernorm_f16_kernel<8>), grid, block, 0, s, x, r, g, b, o, rows, chunks, eps);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, HR_EHIP, "add_layernorm_f16_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out, int64_t n_seq, int T, int heads,
+                         int head_dim, float scale, void* stream) {
+    if (n_seq < 0 || T <= 0 || heads <= 0) return fail(nullptr, HR_EINVAL, "bad attention sizes");
+    if (head_dim != kAttnHeadDim) return fail(nullptr, HR_ELIMIT, "this attention kernel serves head dimension %d only (got %d)", kAttnHeadDim, head_dim);
+    if (T > 4096) return fail(nullptr, HR_ELIMIT, "sequence length %d exceeds 4096", T);
+    if (!d_qkv || !d_out) return fail(nullptr, HR_EINVAL, "null buffer");
+    if (((uintptr_t)d_qkv | (uintptr_t)d_out) & 15) return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
+    if (n_seq == 0) return HR_OK;
+    if (n_seq * heads > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many (sequence, head) pairs");
+    const int n_chunks = (T + 31) / 32;
+    const size_t lds = (size_t)n_chunks * 2 * 64 * sizeof(half8_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e0 = hipFuncSetAttribute((const void*)attention_hd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        if (e0 != hipSuccess) return fail(nullptr, HR_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e0));
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(n_seq * heads), (unsigned)((T + kAttnQueriesPerBlock - 1) / kAttnQueriesPerBlock));
+    hipLaunchKernelGGL(attention_hd32_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_lengths,
+                       (_Float16*)d_out, T, heads, scale * 1.4426950408889634f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "attention_hd32_kernel: %s", hipGetErrorString(e));
     return HR_OK;
 }
 

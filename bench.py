@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-api-concurrent", action="store_true", help="skip the concurrent retrieve() measurement")
+    ap.add_argument("--no-config4-full", action="store_true", help="skip the second timed region with the cross-encoder rerank")
     ap.add_argument("--ingest", action="store_true",
                     help="measure AdvancedRAGPipeline.ingest_documents instead of the search step: synthetic documents of "
                          "~512 tokens through SentenceEncoder (random-init, bge-base shape at --dim 768) + BM25SparseEncoder "
@@ -368,10 +369,16 @@ def main():
 
     # ---- timed region -----------------------------------------------------------------------------------
     ce_note = None
-    if args.rerank == "cross-encoder":
+    ce_model = {}
+
+    def make_cross_encoder(T):
+        """(hook, events, pairs per step) of the cross-encoder leg at T tokens per pair: a random-init MiniLM-L6
+        cross-encoder (PyTorch-ROCm) over the top_k fused candidates of every query, keeping its best rerank_top_k."""
         from advanced_rag.encoders import CrossEncoderModel
-        ce = CrossEncoderModel(device=str(dev), max_len=args.ce_seq_len)
-        T, vocab = args.ce_seq_len, ce.config.vocab_size
+        if "m" not in ce_model:
+            ce_model["m"] = CrossEncoderModel(device=str(dev), max_len=512)
+        ce = ce_model["m"]
+        vocab = ce.config.vocab_size
         # The rerank is per query, not per shard (SURVEY §8(e)): with W ranks each rank scores the fused candidates of
         # its ceil(B / W) queries and one small all-gather (5 ids + scores per query) puts the result on every rank.
         ce_nq = -(-B // world)
@@ -383,8 +390,7 @@ def main():
         types[:, T // 4:] = 1
         mask = torch.ones((ce_pairs, T), dtype=torch.bool, device=dev)
         qslot = torch.arange(ce_q0, ce_q1, device=dev)[:, None, None]
-
-        ce_events = []
+        events = []
 
         def cross_encode(b):
             # synthetic token ids derived from (query slot, fused doc id, position): there is no text behind the
@@ -393,7 +399,7 @@ def main():
             ev0.record(torch.cuda.current_stream(dev))
             _cross_encode(b)
             ev1.record(torch.cuda.current_stream(dev))
-            ce_events.append((ev0, ev1))
+            events.append((ev0, ev1))
 
         def _cross_encode(b):
             fused = b["fused_ids"][ce_q0:ce_q1]
@@ -419,6 +425,11 @@ def main():
             b["ce_ids"] = ids[:B]
             b["ce_scores"] = sc[:B]
 
+        return cross_encode, events, ce_pairs, ce
+
+    if args.rerank == "cross-encoder":
+        T = args.ce_seq_len
+        cross_encode, ce_events, ce_pairs, ce = make_cross_encoder(T)
         ce_note = (f"+ cross-encoder rerank {args.top_k}->{cfg.rerank_top_k}: random-init MiniLM-L6-H384 (PyTorch-ROCm, fp16), "
                    f"{B * args.top_k} pairs x {T} tokens per step" + (f", the queries split over the {world} ranks" if world > 1 else ""))
         if n_fly > 1:
@@ -486,6 +497,46 @@ def main():
         post_us = timed(lambda: nat.post_lists_dev(pa, B, st.cuda_stream))
         alone = {"finish_us": fin_us, "post_lists_us": post_us, "lists_merged_per_modality": eng.n_lists,
                  "note": "back-to-back launches on an idle chip, launch overhead included"}
+
+    # ---- full BASELINE config 4: the same step WITH the cross-encoder rerank 20 -> 5 (reference retrieval.py:518-563,
+    # :651-681), a second short timed region on the same shard, at 128 and at 512 tokens per (query, document) pair
+    config4_full = None
+    if n_fly > 1 and use_sparse and args.rerank == "learned" and not args.no_config4_full and (N, D) == (10_000_000, 768):
+        config4_full = {}
+        for T in (128, 512):
+            hook, evs, pairs, ce_m = make_cross_encoder(T)
+            eng.post_hook = hook
+            k_full, w_full = (10, 3) if T == 128 else (4, 2)
+            for i in range(w_full):
+                step(i)
+            torch.cuda.synchronize()
+            evs.clear()
+            h.kernel_ms()
+            h.set_profiling(1)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(k_full):
+                step(w_full + i)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            el = time.perf_counter() - t1
+            h.set_profiling(0)
+            if world > 1:
+                tt = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            ph = h.kernel_ms()
+            config4_full[f"seq_len_{T}"] = {
+                "value": B * k_full / el, "unit": "queries/s", "ms_per_step": el / k_full * 1e3, "steps": k_full, "warmup": w_full,
+                "cross_encoder": ce_report(ce_m, evs, pairs, T),
+                "dense_scan_ms": round(ph["dense_scan"][0], 4), "sparse_scan_ms": round(ph["sparse_scan"][0], 4)}
+            eng.post_hook = None
+        eng.synchronize()
+        config4_full["note"] = ("hybrid dense+sparse -> RRF -> cross-encoder rerank 20 -> 5: random-init MiniLM-L6-H384 (PyTorch-ROCm fp16 "
+                                "GEMMs + HIP elementwise / attention kernels), synthetic token ids; the forward runs on the finishing stream")
 
     # every rank merges the same gathered lists, so every rank must hold the same fused answer for the last batch
     ranks_agree = None
@@ -600,6 +651,7 @@ def main():
             "cpu_baseline": cpu,
             "kernel_ms": {k: round(v[0], 4) for k, v in phases.items() if v[1]},
             **({"finishing_alone": alone} if alone else {}),
+            **({"config4_full": config4_full} if config4_full else {}),
             "all_lists_proven_exact": flags_exact, **({"ranks_agree": ranks_agree} if ranks_agree is not None else {}),
             "host_enqueue_ms_per_step": host_enqueue / args.steps * 1e3,
         }

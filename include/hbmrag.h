@@ -317,6 +317,13 @@ HR_API int hr_filter_eval_dev(const hr_filter_term* terms, int n_terms, int64_t 
 HR_API int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
                              void* d_out, int64_t rows, int hidden, float eps, void* stream);
 
+/* Self-attention for head dimension 32, from the fused QKV projection's output to the layout the output projection
+ * reads (the PyTorch SDPA call plus the permute / transpose copies around it, in one kernel):
+ *   d_qkv [n_seq][T][3][heads][32] fp16, d_lengths[n_seq] valid tokens per sequence (padding at the tail; NULL = T),
+ *   d_out [n_seq][T][heads * 32] fp16 = softmax(scale * Q K^T, keys < length) V per head, fp32 accumulation. */
+HR_API int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out, int64_t n_seq, int T, int heads,
+                         int head_dim, float scale, void* stream);
+
 /* ---- streams with a compute-unit mask -------------------------------------------
  * A HIP stream whose kernels may only occupy the compute units named by `cu_mask` (bit i of word i/32 = CU i;
  * n_words 32-bit words; on gfx950 consecutive bits alternate over the 8 XCDs) — the way to keep a latency-bound

@@ -1,0 +1,58 @@
+"""Ad-hoc probe (not a test): forward pass of the cross-encoder leg (2560 pairs = 128 queries x 20 candidates) at a given
+sequence length, in the arrangements under study; prints ms per forward, share of the fp16 MFMA peak and the top kernels.
+    python tests/perf_probe_ce.py [T=128] [pairs=2560]"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "advanced-rag-milvus_amd"))
+from advanced_rag.encoders import CrossEncoderModel, EncoderConfig  # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 2560
+dev = torch.device("cuda:0")
+ids = torch.randint(1000, 30000, (P, T), device=dev)
+ids[:, 0] = 101
+types = torch.zeros((P, T), dtype=torch.long, device=dev)
+types[:, T // 4:] = 1
+mask = torch.ones((P, T), dtype=torch.bool, device=dev)
+
+
+def run(name, ce, tunable=False, profile=False):
+    if tunable:
+        torch.cuda.tunable.enable(True)
+        torch.cuda.tunable.set_max_tuning_duration(200)
+        torch.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", "tunableop_ce.csv"))
+    with torch.inference_mode():
+        t0 = time.time()
+        for _ in range(3):
+            ce.module(ids, types, mask)
+        torch.cuda.synchronize()
+        warm = time.time() - t0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ce.module(ids, types, mask)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        tf = P * ce.flops_per_pair(T) / (ms * 1e-3) / 1e12
+        print(f"{name:34s} {ms:8.3f} ms/forward  {tf:7.1f} TFLOP/s = {tf / 2500:.3f} of the fp16 MFMA peak (warm-up {warm:.1f}s)", flush=True)
+        if profile:
+            from torch.profiler import ProfilerActivity, profile as prof
+            with prof(activities=[ProfilerActivity.CUDA]) as p:
+                for _ in range(3):
+                    ce.module(ids, types, mask)
+                torch.cuda.synchronize()
+            print(p.key_averages().table(sort_by="cuda_time_total", row_limit=14, max_name_column_width=90), flush=True)
+    if tunable:
+        torch.cuda.tunable.enable(False)
+
+
+run("erf gelu (round 2 arrangement)", CrossEncoderModel(EncoderConfig(gelu="erf"), device=str(dev), max_len=512), profile=True)
+ce = CrossEncoderModel(EncoderConfig(gelu="tanh"), device=str(dev), max_len=512)
+run("tanh gelu in the GEMM epilogue", ce, profile=True)
+run("... + TunableOp", ce, tunable=True)

@@ -208,3 +208,34 @@ def test_device_embedding_table_evicts_fifo_and_keeps_values(gpu):
         assert torch.equal(t.lookup(k).cpu(), vecs[k])
     assert torch.equal(old_k0.cpu(), vecs["k0"])   # the copy taken before the eviction still holds k0's bytes
     assert t.store("k5", vecs["k5"]).data_ptr() == t.lookup("k5").data_ptr()   # re-store of a live key: same slot
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_seq,T,heads", [(3, 16, 1), (5, 40, 4), (7, 128, 12), (2, 200, 3), (2, 512, 12), (1, 8, 2)])
+def test_attention_hd32_kernel_matches_sdpa_fp32(gpu, n_seq, T, heads):
+    """hr_attention_f16_dev (head dimension 32: QK^T, masked online softmax and PV on the MFMA units, from the fused
+    QKV buffer to the [tokens, hidden] layout) against PyTorch's scaled_dot_product_attention in fp32 on the same
+    fp16-rounded inputs, ragged sequence lengths (keys at or beyond the length masked): within fp16 output rounding."""
+    from advanced_rag import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(n_seq * 1000 + T)
+    H = heads * 32
+    qkv = (torch.randn((n_seq, T, 3, heads, 32), device="cuda", generator=g) * 1.5).half()
+    lengths = torch.randint(1, T + 1, (n_seq,), device="cuda", generator=g).to(torch.int32)
+    lengths[0] = T
+    out = torch.full((n_seq, T, H), float("nan"), dtype=torch.float16, device="cuda")
+    nat.attention_f16_dev(qkv.data_ptr(), lengths.data_ptr(), out.data_ptr(), n_seq, T, heads, 32, 32 ** -0.5,
+                          torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    q, k, v = qkv.float().permute(2, 0, 3, 1, 4)
+    key_ok = torch.arange(T, device="cuda")[None, :] < lengths[:, None]
+    bias = torch.zeros((n_seq, 1, 1, T), device="cuda").masked_fill(~key_ok[:, None, None, :], float("-inf"))
+    want = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=bias).transpose(1, 2).reshape(n_seq, T, H)
+    assert torch.isfinite(out).all()
+    assert torch.allclose(out.float(), want, atol=4e-3, rtol=1e-2), (out.float() - want).abs().max()
+    # no lengths = every key is valid
+    nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), n_seq, T, heads, 32, 32 ** -0.5, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(n_seq, T, H)
+    assert torch.allclose(out.float(), want, atol=4e-3, rtol=1e-2)
+    with pytest.raises(nat.HbmRagError):
+        nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), n_seq, T, heads, 64, 0.125, 0)
