@@ -48,6 +48,9 @@ class SearchCoalescer:
         self._thread: Optional[threading.Thread] = None
         self._lock = threading.Lock()
         self._closed = False
+        # torchrun form (shards.CollectiveShardSet): a round of the front = one round of the shard set, i.e. ONE
+        # broadcast + ONE gather for all the dense and sparse searches that share (top_k, filter, drop ratio)
+        self.collective = hasattr(getattr(manager, "_main", None), "round")
         self.stats = {"rounds": 0, "requests": 0, "dense_launches": 0, "sparse_launches": 0, "fuse_launches": 0,
                       "max_batch_seen": 0, "redone_unproven": 0, "busy_s": 0.0}
 
@@ -58,7 +61,8 @@ class SearchCoalescer:
             if self._closed:
                 raise RuntimeError("search front is closed")
             if self._thread is None:
-                self._thread = threading.Thread(target=self._run, name="search-coalescer", daemon=True)
+                self._thread = threading.Thread(target=self._run_collective if self.collective else self._run,
+                                                name="search-coalescer", daemon=True)
                 self._thread.start()
         self._q.put(req)
         return req.future
@@ -74,26 +78,27 @@ class SearchCoalescer:
     # ------------------------------------------------------------------ worker
     def _collect(self) -> Optional[List[_Request]]:
         """The requests of one round: everything already queued (what piled up while the previous round ran), plus what
-        arrives within `window_s` of the LAST arrival, at most 4 windows after the first request.  The wait is a spin on
-        the queue, not a sleep: a timed sleep of 20 us costs ~75 us of timer slack, and a lone retrieve() pays every
-        microsecond of this twice (search round, fusion round)."""
+        arrives within `window_s` of the LAST arrival, at most 4 windows after the first request.  The wait is a blocking
+        get with a timeout — it releases the GIL, so the event loop can go on submitting, and returns the moment a request
+        arrives; a lone retrieve() pays the expiry of one window per round (search round, fusion round)."""
         first = self._q.get()
         if first is None:
             return None
         reqs = [first]
-        t_first = t_last = time.perf_counter()
+        t_first = time.perf_counter()
         while len(reqs) < 4 * self.max_batch:
             try:
                 r = self._q.get_nowait()
             except queue.Empty:
-                now = time.perf_counter()
-                if now - t_last >= self.window_s or now - t_first >= 4 * self.window_s:
+                if time.perf_counter() - t_first >= 4 * self.window_s:
                     break
-                continue
+                try:
+                    r = self._q.get(timeout=self.window_s)
+                except queue.Empty:
+                    break
             if r is None:
                 self._q.put(None)  # close() arrived behind real work: finish this round first
                 break
-            t_last = time.perf_counter()
             reqs.append(r)
         return reqs
 
@@ -137,6 +142,54 @@ class SearchCoalescer:
                     for r in chunk:
                         if not r.future.done():
                             r.future.set_exception(e)
+            self.stats["busy_s"] += time.perf_counter() - t0
+
+    def _run_collective(self):
+        """Rounds of the torchrun form: the dense and the sparse searches of the callers that share (top_k, filter
+        expression, drop ratio) travel in one packet; other combinations take a round of their own."""
+        cs = self.mgr._main
+        while True:
+            reqs = self._collect()
+            if reqs is None:
+                return
+            t0 = time.perf_counter()
+            self.stats["rounds"] += 1
+            self.stats["requests"] += len(reqs)
+            groups: Dict[Tuple, Dict[str, List[_Request]]] = {}
+            for r in reqs:
+                if r.kind == "fuse":
+                    try:
+                        r.future.set_result(self.mgr._fuse_rows_blocking(r.payload, r.key))
+                    except Exception as e:
+                        r.future.set_exception(e)
+                    continue
+                coll_name, top_k, expr, params_key = r.key
+                drop = float(dict(params_key).get("drop_ratio_search", 0.0)) if r.kind == "sparse" else None
+                groups.setdefault((top_k, expr), {}).setdefault((r.kind, drop), []).append(r)
+            for (top_k, expr), by_kind in groups.items():
+                dense = next((v for (kind, _), v in by_kind.items() if kind == "dense"), [])
+                sparse_sets = [(d, v) for (kind, d), v in by_kind.items() if kind == "sparse"] or [(0.0, [])]
+                for n_round, (drop, sparse) in enumerate(sparse_sets):
+                    dn = dense if n_round == 0 else []
+                    for c0 in range(0, max(len(dn), len(sparse), 1), 64):
+                        d_chunk, s_chunk = dn[c0:c0 + 64], sparse[c0:c0 + 64]
+                        if not d_chunk and not s_chunk:
+                            continue
+                        try:
+                            keep = self.mgr._row_mask(expr)
+                            q = np.stack([np.asarray(r.payload.detach().cpu().numpy() if hasattr(r.payload, "detach") else r.payload,
+                                                     dtype=np.float32).reshape(-1) for r in d_chunk]) if d_chunk else None
+                            res = cs.round(q, [r.payload for r in s_chunk] if s_chunk else None, top_k, drop or 0.0, keep)
+                            self.stats["dense_launches"] += 1 if d_chunk else 0
+                            self.stats["sparse_launches"] += 1 if s_chunk else 0
+                            self.stats["max_batch_seen"] = max(self.stats["max_batch_seen"], len(d_chunk), len(s_chunk))
+                            for chunk, lists in ((d_chunk, res[0]), (s_chunk, res[1])):
+                                for i, r in enumerate(chunk):
+                                    r.future.set_result((lists[0][i], lists[1][i]))
+                        except Exception as e:
+                            for r in d_chunk + s_chunk:
+                                if not r.future.done():
+                                    r.future.set_exception(e)
             self.stats["busy_s"] += time.perf_counter() - t0
 
     def _one_by_one(self, kind: str, key: Tuple, chunk: List[_Request]):

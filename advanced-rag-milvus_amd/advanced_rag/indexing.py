@@ -272,16 +272,8 @@ class MilvusIndexManager:
             if m is not None:
                 keep = np.unpackbits(m.cpu().numpy(), bitorder="little")[:n].astype(bool)
         else:
-            if expr and self._synthetic_rows:
-                # bulk-ingested rows carry no payload columns; what their synthetic id encodes can still be filtered on:
-                # chunk_index = row % 10 (synthetic_id), derived on the fly
-                fields = {f for f, _, _ in _filters.parse(expr)}
-                if fields - {"chunk_index"}:
-                    raise ValueError("this shard was bulk-ingested without payload columns: only chunk_index (= row % 10) "
-                                     f"can be filtered on, not {sorted(fields - {'chunk_index'})}")
-                keep = _filters.evaluate(expr, {"chunk_index": np.arange(n, dtype=np.int64) % 10}, n)
-            elif expr:
-                keep = _filters.evaluate(expr, self._columns(), n)
+            if expr:
+                keep = self._host_predicate(expr, n)
             if self._deleted is not None and self._deleted[:n].any():
                 alive = np.ones(n, dtype=bool)
                 alive[:self._deleted.shape[0]] = ~self._deleted[:n]
@@ -291,13 +283,25 @@ class MilvusIndexManager:
         self._mask_cache[key] = keep
         return keep
 
+    def _host_predicate(self, expr: str, n: int) -> np.ndarray:
+        """filters.evaluate over the host columns (collections without a device: CPU tests, oracle-backed shards)."""
+        if self._synthetic_rows:
+            # bulk-ingested rows carry no payload columns; what their synthetic id encodes can still be filtered on:
+            # chunk_index = row % 10 (synthetic_id), derived on the fly
+            fields = {f for f, _, _ in _filters.parse(expr)}
+            if fields - {"chunk_index"}:
+                raise ValueError("this shard was bulk-ingested without payload columns: only chunk_index (= row % 10) "
+                                 f"can be filtered on, not {sorted(fields - {'chunk_index'})}")
+            return _filters.evaluate(expr, {"chunk_index": np.arange(n, dtype=np.int64) % 10}, n)
+        return _filters.evaluate(expr, self._columns(), n)
+
     def _tombstone(self, expr: str):
         n = self.num_rows
         dev = self._filters_on_device()
         if dev is not None:
             hit = np.unpackbits(dev.evaluate(expr, n)[0].cpu().numpy(), bitorder="little")[:n].astype(bool)
         else:
-            hit = _filters.evaluate(expr, self._columns(), n)
+            hit = self._host_predicate(expr, n)
         if self._deleted is None or self._deleted.shape[0] < n:
             grown = np.zeros(n, dtype=bool)
             if self._deleted is not None:
@@ -652,7 +656,10 @@ class MilvusIndexManager:
     def _coalescer(self, coll):
         """The batching front, or None when this collection cannot use it (spread over several shard handles: those
         searches fan out per shard and merge on the host)."""
-        if not self.coalesce or getattr(coll.handle, "n_shards", 1) != 1 or not hasattr(coll.handle, "handles"):
+        if not self.coalesce:
+            return None
+        collective = hasattr(coll.handle, "round")          # torchrun form: rounds of one broadcast + one gather
+        if not collective and (getattr(coll.handle, "n_shards", 1) != 1 or not hasattr(coll.handle, "handles")):
             return None
         if self._front is None:
             from .batching import SearchCoalescer
@@ -731,7 +738,7 @@ class MilvusIndexManager:
             raise RuntimeError("no shard handle")
         row_to_id, lists, key = self._fuse_inputs(row_lists, id_lists, weights, rrf_k)
         front = self._coalescer(self.collections["semantic_index"]) if "semantic_index" in self.collections else None
-        if front is None or max(len(x) for x in lists) > 256:
+        if front is None or front.collective or max(len(x) for x in lists) > 256:
             return self._fuse_output(row_to_id, *await asyncio.to_thread(self._fuse_rows_blocking, lists, key))
         rows, scores, methods = await asyncio.wait_for(asyncio.wrap_future(front.submit("fuse", key, lists)),
                                                        timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)

@@ -241,19 +241,31 @@ class ShardSet:
 
 
 class CollectiveShardSet:
-    """The torchrun form: one PROCESS per GPU, each owning the shard(s) of a contiguous global row range, searched
-    as one collection from rank 0.
+    """The torchrun form: one PROCESS per GPU, each owning the shard of a contiguous global row range, searched as one
+    collection from rank 0 — the reference's `num_shards` are invisible to the caller and cost it one RPC
+    (indexing.py:232-239, :439-551); here a round of searches costs TWO collectives:
 
-    Rank 0 is the front end (it owns the payload columns and answers `search`); the other ranks run `serve()`.
-    One search = broadcast of a fixed-size header, broadcast of the query (+ the packed filter mask, if any), the
-    per-rank HIP search, ONE gather of the packed per-rank lists to rank 0, the same merge as `ShardSet`.  The
-    collectives are torch.distributed's (backend "nccl" = RCCL over xGMI on a GPU node; "gloo" in the CPU tests and
-    one-GPU rehearsals); searches are serialised by a lock, so every rank sees the same sequence of commands.
+      1. ONE broadcast of a fixed-size packet (header + dense queries + sparse queries as CSR + the id of the filter
+         mask): every rank learns what to search;
+      2. every rank runs the dense and / or the sparse search of the round on its shard (device forms on a GPU shard,
+         unproven lists repaired locally through the host form);
+      3. ONE gather of the packed per-rank lists (both modalities) to rank 0, which merges them by (score desc, row asc).
 
-    The local shard must already carry its global row numbers (ShardHandle.set_row_offset(first_row)), i.e. a
-    local ShardSet of one handle; `first_row`/`n_local` say which slice of a global filter mask is this rank's."""
+    A round carries the searches of one or many retrieve() calls (the manager's batching front packs concurrent
+    callers), so a lone retrieve() = 1 broadcast + 1 gather.  A filter's packed row mask travels ONCE, in an extra
+    broadcast of the round that first uses it; every rank keeps its slice under the mask's id (same LRU on all ranks).
+    Rank 0 validates and packs the whole round BEFORE the first collective and every rank always reaches the gather — a
+    failing rank contributes empty lists and an error flag that rank 0 raises — so nobody is left waiting in a
+    collective.  Collectives are torch.distributed's (backend "nccl" = RCCL over xGMI on a GPU node; "gloo" in the CPU
+    tests and one-GPU rehearsals); rounds are serialised by a lock, so every rank sees the same sequence.
 
-    OP_STOP, OP_DENSE, OP_SPARSE = 0, 1, 2
+    The local shard must already carry its global row numbers (ShardHandle.set_row_offset(first_row)), i.e. a local
+    ShardSet of one handle; `first_row` says where this rank's rows sit in a global filter mask."""
+
+    OP_STOP, OP_ROUND = 0, 1
+    HEADER = 16                     # int64 words
+    PACKET_BYTES = 1 << 20          # header + queries of one round (128 x (768-d dense + 100-term sparse) = 0.5 MB)
+    MAX_MASKS = 8
 
     def __init__(self, local: ShardSet, first_row: int, dist, group=None, device=None):
         import threading
@@ -269,6 +281,11 @@ class CollectiveShardSet:
         n = torch.tensor([local.num_rows, local.num_sparse_rows], dtype=torch.int64, device=self.dev)
         dist.all_reduce(n, group=group)
         self._n_rows, self._n_sparse = int(n[0]), int(n[1])
+        self._packet = torch.zeros(self.PACKET_BYTES, dtype=torch.uint8, device=self.dev)
+        self._masks = {}            # mask id -> this rank's boolean slice (LRU, same order on every rank)
+        self._mask_ids = {}         # rank 0: id(filter array) -> (mask id, the array: keeps the id alive)
+        self._next_mask_id = 1
+        self.n_collectives = 0      # broadcasts + gathers issued (tests count them)
 
     # shape, as ShardSet
     n_shards = property(lambda self: self.world)
@@ -284,97 +301,181 @@ class CollectiveShardSet:
     def close(self):
         self.local.close()
 
+    def save(self, path_of_shard) -> None:
+        raise NotImplementedError("snapshots of the torchrun form: save each rank's local shard (manager._main.local.save)")
+
+    def row_maps(self):
+        raise NotImplementedError("the torchrun form keeps one contiguous row range per rank, not row maps")
+
     # ------------------------------------------------------------------ protocol
     def _bcast(self, t):
+        self.n_collectives += 1
         self.dist.broadcast(t, src=0, group=self.group)
         return t
 
-    def _header(self, values=None):
-        t = self.torch
-        h = t.zeros(8, dtype=t.int64, device=self.dev)
-        if values is not None:
-            h[: len(values)] = t.tensor(values, dtype=t.int64)
-        return self._bcast(h).tolist()
-
-    def _exchange_mask(self, keep, n_rows: int, has_mask: bool):
-        """rank 0 broadcasts the packed filter over GLOBAL rows; every rank cuts out its own rows."""
-        if not has_mask:
-            return None
-        t = self.torch
-        packed = t.from_numpy(np.packbits(keep, bitorder="little")).to(self.dev) if self.rank == 0 else \
-            t.empty((n_rows + 7) // 8, dtype=t.uint8, device=self.dev)
-        bits = np.unpackbits(self._bcast(packed).cpu().numpy(), bitorder="little")[:n_rows].astype(bool)
-        n_local = self.local.num_rows if self.local.num_rows else self.local.num_sparse_rows
-        return bits[self.first_row:self.first_row + n_local]
-
-    def _collect(self, ids: np.ndarray, scores: np.ndarray, k: int):
-        """ONE gather: [B, 2k] int64 per rank = ids, then the fp32 score bits."""
-        t = self.torch
-        B = ids.shape[0]
-        pack = np.concatenate([ids.astype(np.int64), scores.astype(np.float32).view(np.int32).astype(np.int64)], axis=1)
-        mine = t.from_numpy(np.ascontiguousarray(pack)).to(self.dev)
-        parts = [t.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
-        self.dist.gather(mine, parts, dst=0, group=self.group)
-        if self.rank != 0:
-            return None
-        parts = [p.cpu().numpy() for p in parts]
-        return merge_lists([p[:, :k] for p in parts],
-                           [p[:, k:].astype(np.int32).view(np.float32).reshape(B, k) for p in parts], k)
-
-    def _run(self, op: int, B: int, k: int, extra: int, has_mask: bool, drop_bits: int, payload, keep):
-        t = self.torch
-        if op == self.OP_DENSE:
-            dim = extra
-            q = payload if self.rank == 0 else t.empty((B, dim), dtype=t.float32, device=self.dev)
-            q = self._bcast(q).cpu().numpy()
-            local_keep = self._exchange_mask(keep, self._n_rows, has_mask)
-            ids, sc = self.local.search_dense(q, k, local_keep)
-        else:
-            nnz = extra
-            if self.rank == 0:
-                ptr, idx, val = payload
+    def _pack_round(self, dense_q, sparse_queries, k: int, drop: float, keep):
+        """rank 0: the whole round as one byte packet (numpy); raises BEFORE any collective if something is wrong."""
+        Bd = 0 if dense_q is None else int(dense_q.shape[0])
+        Bs = 0 if sparse_queries is None else len(sparse_queries)
+        parts, dim = [], 0
+        if Bd:
+            dense_q = np.ascontiguousarray(dense_q, dtype=np.float32)
+            dim = dense_q.shape[1]
+            parts.append(dense_q.view(np.uint8).reshape(-1))
+        nnz = 0
+        if Bs:
+            ptr = np.zeros(Bs + 1, dtype=np.int64)
+            for b, (qi, _) in enumerate(sparse_queries):
+                ptr[b + 1] = ptr[b] + len(qi)
+            nnz = int(ptr[-1])
+            idx = np.concatenate([np.asarray(qi, np.int32) for qi, _ in sparse_queries]) if nnz else np.zeros(0, np.int32)
+            val = np.concatenate([np.asarray(qv, np.float32) for _, qv in sparse_queries]) if nnz else np.zeros(0, np.float32)
+            if idx.shape != val.shape:
+                raise ValueError("sparse query indices/values length mismatch")
+            parts += [ptr.view(np.uint8), idx.view(np.uint8), val.view(np.uint8)]
+        mask_id, mask_new, mask_bytes = 0, 0, None
+        if keep is not None:
+            ent = self._mask_ids.get(id(keep))
+            if ent is None or ent[0] not in self._masks:
+                mask_id, mask_new = self._next_mask_id, 1
+                self._next_mask_id += 1
+                self._mask_ids = {key: v for key, v in self._mask_ids.items() if v[0] in self._masks}
+                self._mask_ids[id(keep)] = (mask_id, keep)
+                mask_bytes = np.packbits(np.asarray(keep, dtype=bool), bitorder="little")
             else:
-                ptr = t.empty(B + 1, dtype=t.int64, device=self.dev)
-                idx = t.empty(nnz, dtype=t.int32, device=self.dev)
-                val = t.empty(nnz, dtype=t.float32, device=self.dev)
-            ptr, idx, val = (self._bcast(x).cpu().numpy() for x in (ptr, idx, val))
-            local_keep = self._exchange_mask(keep, self._n_sparse, has_mask)
-            queries = [(idx[ptr[b]:ptr[b + 1]], val[ptr[b]:ptr[b + 1]]) for b in range(B)]
-            drop = float(np.array([drop_bits], dtype=np.int64).view(np.float64)[0])
-            ids, sc = self.local.search_sparse(queries, k, drop, local_keep)
-        return self._collect(ids, sc, k)
+                mask_id = ent[0]
+        hdr = np.zeros(self.HEADER, dtype=np.int64)
+        hdr[:10] = [self.OP_ROUND, Bd, Bs, k, dim, nnz, int(np.array([drop], dtype=np.float64).view(np.int64)[0]), mask_id,
+                    mask_new, 0 if mask_bytes is None else mask_bytes.size]
+        body = np.concatenate([hdr.view(np.uint8)] + parts) if parts else hdr.view(np.uint8)
+        if body.size > self.PACKET_BYTES:
+            raise ValueError(f"a round of {Bd} dense + {Bs} sparse queries needs {body.size} bytes; the packet holds {self.PACKET_BYTES}")
+        return body, mask_bytes
+
+    def _send_packet(self, body: Optional[np.ndarray]):
+        """ONE broadcast of the fixed-size packet; returns its bytes as numpy on every rank."""
+        t = self.torch
+        if self.rank == 0:
+            host = np.zeros(self.PACKET_BYTES, dtype=np.uint8)
+            host[: body.size] = body
+            self._packet.copy_(t.from_numpy(host))
+        self._bcast(self._packet)
+        if self.rank == 0:
+            return host
+        hdr = self._packet[: self.HEADER * 8].cpu().numpy().view(np.int64)   # then only the bytes the round uses
+        need = self.HEADER * 8 + int(hdr[1]) * int(hdr[4]) * 4 + (int(hdr[2]) + 1) * 8 * (1 if hdr[2] else 0) + int(hdr[5]) * 8
+        return self._packet[: min(need, self.PACKET_BYTES)].cpu().numpy()
+
+    def _mask_slice(self, hdr, mask_bytes_rank0):
+        """This rank's boolean slice of the round's filter (None = no filter); receives a new mask if the round carries one."""
+        t = self.torch
+        mask_id, mask_new, mask_len = int(hdr[7]), int(hdr[8]), int(hdr[9])
+        if mask_id == 0:
+            return None
+        if mask_new:
+            buf = t.from_numpy(mask_bytes_rank0).to(self.dev) if self.rank == 0 else t.empty(mask_len, dtype=t.uint8, device=self.dev)
+            bits = np.unpackbits(self._bcast(buf).cpu().numpy(), bitorder="little").astype(bool)
+            n_local = max(self.local.num_rows, self.local.num_sparse_rows)
+            if bits.size < self.first_row + n_local:
+                raise ValueError(f"filter mask covers {bits.size} rows, this rank holds rows up to {self.first_row + n_local}")
+            if len(self._masks) >= self.MAX_MASKS:
+                self._masks.pop(next(iter(self._masks)))
+            self._masks[mask_id] = bits[self.first_row: self.first_row + n_local]
+        return self._masks[mask_id]
+
+    def _local_round(self, pkt: np.ndarray, hdr, keep_local):
+        """Run this rank's part of a round -> int64 [2 + n_mod * B * k * 2]: status, then ids and score bits per modality."""
+        Bd, Bs, k, dim, nnz = (int(x) for x in hdr[1:6])
+        drop = float(np.array([hdr[6]], dtype=np.int64).view(np.float64)[0])
+        off = self.HEADER * 8
+        out = []
+        if Bd:
+            q = pkt[off: off + Bd * dim * 4].view(np.float32).reshape(Bd, dim)
+            off += Bd * dim * 4
+            kd = None if keep_local is None else keep_local[: self.local.num_rows]
+            out.append(self.local.search_dense(q, k, kd))
+        if Bs:
+            ptr = pkt[off: off + (Bs + 1) * 8].view(np.int64)
+            off += (Bs + 1) * 8
+            idx = pkt[off: off + nnz * 4].view(np.int32)
+            off += nnz * 4
+            val = pkt[off: off + nnz * 4].view(np.float32)
+            queries = [(idx[ptr[b]:ptr[b + 1]], val[ptr[b]:ptr[b + 1]]) for b in range(Bs)]
+            ks = None if keep_local is None else keep_local[: self.local.num_sparse_rows]
+            out.append(self.local.search_sparse(queries, k, drop, ks))
+        return out
+
+    def _round(self, body, mask_bytes):
+        """Both sides of a round after rank 0 has packed it.  Returns the merged lists on rank 0."""
+        t = self.torch
+        pkt = self._send_packet(body)
+        hdr = pkt[: self.HEADER * 8].view(np.int64)
+        if int(hdr[0]) == self.OP_STOP:
+            return False
+        Bd, Bs, k = int(hdr[1]), int(hdr[2]), int(hdr[3])
+        n_vals = (Bd + Bs) * k
+        mine = np.zeros(2 + 2 * n_vals, dtype=np.int64)
+        mine[2: 2 + n_vals] = -1
+        err = None
+        try:
+            lists = self._local_round(pkt, hdr, self._mask_slice(hdr, mask_bytes))
+            ids = np.concatenate([li.reshape(-1) for li, _ in lists]).astype(np.int64)
+            sc = np.concatenate([s.reshape(-1) for _, s in lists]).astype(np.float32)
+            mine[2: 2 + n_vals] = ids
+            mine[2 + n_vals:] = sc.view(np.int32).astype(np.int64)
+        except Exception as e:   # still reach the gather: nobody may be left waiting in a collective
+            err = e
+            mine[0] = 1
+        mine_t = t.from_numpy(mine).to(self.dev)
+        parts = [t.empty_like(mine_t) for _ in range(self.world)] if self.rank == 0 else None
+        self.n_collectives += 1
+        self.dist.gather(mine_t, parts, dst=0, group=self.group)
+        if err is not None and self.rank != 0:
+            import logging
+            logging.getLogger(__name__).error("rank %d failed its part of a search round: %s", self.rank, err)
+        if self.rank != 0:
+            return True
+        if err is not None:
+            raise err
+        parts = [p.cpu().numpy() for p in parts]
+        bad = [r for r, p in enumerate(parts) if p[0] != 0]
+        if bad:
+            raise RuntimeError(f"search round failed on rank(s) {bad}")
+        out, o = [], 2
+        for B in (Bd, Bs):
+            if not B:
+                out.append(None)
+                continue
+            ids = [p[o: o + B * k].reshape(B, k) for p in parts]
+            scs = [p[2 + n_vals + (o - 2): 2 + n_vals + (o - 2) + B * k].astype(np.int32).view(np.float32).reshape(B, k) for p in parts]
+            out.append(merge_lists(ids, scs, k))
+            o += B * k
+        return out
 
     # ------------------------------------------------------------------ rank 0
-    def search_dense(self, q: np.ndarray, k: int, keep: Optional[np.ndarray] = None):
-        t = self.torch
-        q = np.ascontiguousarray(np.atleast_2d(q), dtype=np.float32)
+    def round(self, dense_q: Optional[np.ndarray], sparse_queries, k: int, drop_ratio: float = 0.0, keep: Optional[np.ndarray] = None):
+        """One round = one broadcast + one gather: dense_q [Bd, dim] and / or Bs sparse queries, all with the same k and
+        filter -> ((dense ids, scores) | None, (sparse ids, scores) | None), global rows, merged over the ranks."""
+        if dense_q is not None:
+            dense_q = np.ascontiguousarray(np.atleast_2d(dense_q), dtype=np.float32)
         with self._lock:
-            self._header([self.OP_DENSE, q.shape[0], k, q.shape[1], int(keep is not None), 0])
-            return self._run(self.OP_DENSE, q.shape[0], k, q.shape[1], keep is not None, 0,
-                             t.from_numpy(q).to(self.dev), keep)
+            body, mask_bytes = self._pack_round(dense_q, sparse_queries, int(k), float(drop_ratio), keep)   # may raise: no collective yet
+            return self._round(body, mask_bytes)
+
+    def search_dense(self, q: np.ndarray, k: int, keep: Optional[np.ndarray] = None):
+        return self.round(q, None, k, 0.0, keep)[0]
 
     def search_sparse(self, queries, k: int, drop_ratio: float = 0.0, keep: Optional[np.ndarray] = None):
-        t = self.torch
-        ptr = np.zeros(len(queries) + 1, dtype=np.int64)
-        for b, (qi, _) in enumerate(queries):
-            ptr[b + 1] = ptr[b] + len(qi)
-        idx = np.concatenate([np.asarray(qi, np.int32) for qi, _ in queries]) if ptr[-1] else np.zeros(0, np.int32)
-        val = np.concatenate([np.asarray(qv, np.float32) for _, qv in queries]) if ptr[-1] else np.zeros(0, np.float32)
-        drop_bits = int(np.array([drop_ratio], dtype=np.float64).view(np.int64)[0])
-        with self._lock:
-            self._header([self.OP_SPARSE, len(queries), k, int(ptr[-1]), int(keep is not None), drop_bits])
-            payload = tuple(t.from_numpy(x).to(self.dev) for x in (ptr, idx, val))
-            return self._run(self.OP_SPARSE, len(queries), k, int(ptr[-1]), keep is not None, drop_bits, payload, keep)
+        return self.round(None, list(queries), k, drop_ratio, keep)[1]
 
     def stop_workers(self):
         with self._lock:
-            self._header([self.OP_STOP])
+            hdr = np.zeros(self.HEADER, dtype=np.int64)
+            hdr[0] = self.OP_STOP
+            self._send_packet(hdr.view(np.uint8))
 
     # ------------------------------------------------------------------ ranks > 0
     def serve(self):
-        """Answer rank 0's searches until it sends OP_STOP."""
-        while True:
-            op, B, k, extra, has_mask, drop_bits, _, _ = self._header()
-            if op == self.OP_STOP:
-                return
-            self._run(int(op), int(B), int(k), int(extra), bool(has_mask), int(drop_bits), None, None)
+        """Answer rank 0's rounds until it sends OP_STOP."""
+        while self._round(None, None):
+            pass

@@ -345,9 +345,12 @@ def main():
         mask[: n_s // 8] = 0xFF
         for r in range(n_s // 8 * 8, n_s):
             mask[r >> 3] |= 1 << (r & 7)
-        n_gate = 4
+        n_gate = 32
         gids, gsc = h.search_dense(Q[0][:n_gate], kp, mask)
-        oids, osc = oracle.dense_search(Xs, Q[0][:n_gate], kp, oracle.COSINE)
+        # (the oracle is single-threaded C; its per-query calls release the GIL, so the gate's queries run side by side)
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 8)) as ex:
+            parts = list(ex.map(lambda b: oracle.dense_search(Xs, Q[0][b:b + 1], kp, oracle.COSINE), range(n_gate)))
+        oids, osc = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         ok = bool(np.array_equal(gids, oids) and np.array_equal(gsc.view(np.uint32), osc.view(np.uint32)))
         fused_ok = True
         if use_sparse:
@@ -355,7 +358,9 @@ def main():
             s_val = np.concatenate([p[2] for p in sample_sparse])
             s_ptr = np.concatenate([[0], np.cumsum(np.concatenate([np.diff(p[0]) for p in sample_sparse]))]).astype(np.int64)
             sids, ssc = h.search_sparse(SQ[0][:n_gate], kp, 0.2, mask)
-            osids, ossc = oracle.sparse_search(s_ptr, s_idx, s_val, SQ[0][:n_gate], kp, 0.2)
+            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 8)) as ex:
+                parts = list(ex.map(lambda b: oracle.sparse_search(s_ptr, s_idx, s_val, SQ[0][b:b + 1], kp, 0.2), range(n_gate)))
+            osids, ossc = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
             ok = ok and bool(np.array_equal(sids, osids) and np.array_equal(ssc.view(np.uint32), ossc.view(np.uint32)))
             for i in range(n_gate):
                 fi, fs, _ = h.fuse_rrf(gids[i], sids[i][sids[i] >= 0], (), cfg.dense_weight, cfg.sparse_weight, 0.2, 60)

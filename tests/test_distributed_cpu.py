@@ -222,6 +222,48 @@ def _collective_worker(rank, world, port, ret):
             fi, fs, _ = oracle.rrf(di[0], si[0][si[0] >= 0], (), 0.7, 0.3, 0.2, 60)
             assert [o["id"] for o in out] == [MilvusIndexManager.synthetic_id(int(r)) for r in fi[:20]]
             assert [o["score"] for o in out] == [float(s) for s in fs[:20]]
+        # one broadcast + one gather per retrieve(): the batching front packs the dense and the sparse search of a call
+        # into one round; a filter's mask travels once (an extra broadcast in the round that first uses it)
+        retr = HybridRetriever(mgr, RetrievalConfig(top_k=20))
+        c0 = cs.n_collectives
+        asyncio.run(retr.retrieve("1", profile_hint="default"))
+        assert cs.n_collectives - c0 == 2, cs.n_collectives - c0
+        flt = {"chunk_index": {"$lt": 5}}
+        keep5 = (np.arange(n) % 10) < 5
+        c0 = cs.n_collectives
+        out = asyncio.run(retr.retrieve("2", filters=flt, profile_hint="default"))
+        assert cs.n_collectives - c0 == 3                        # + the mask, once
+        c0 = cs.n_collectives
+        out2 = asyncio.run(retr.retrieve("2", filters=flt, profile_hint="default"))
+        assert cs.n_collectives - c0 == 2 and [o["id"] for o in out2] == [o["id"] for o in out]
+        p5 = np.packbits(keep5, bitorder="little")
+        di, _ = oracle.dense_search(X, Q[2:3], 40, oracle.COSINE, p5)
+        si, _ = oracle.sparse_search(ptr, idx, val, SQ[2:3], 40, 0.2, p5)
+        fi, fs, _ = oracle.rrf(di[0], si[0][si[0] >= 0], (), 0.7, 0.3, 0.2, 60)
+        assert [o["id"] for o in out] == [MilvusIndexManager.synthetic_id(int(r)) for r in fi[:20]]
+        assert all(o["metadata"]["chunk_index"] < 5 for o in out)
+        # tombstones ride the same masks
+        asyncio.run(mgr.delete_by_filter("semantic_index", "chunk_index == 3"))
+        out3 = asyncio.run(retr.retrieve("2", filters=flt, profile_hint="default"))
+        pd = np.packbits(keep5 & ((np.arange(n) % 10) != 3), bitorder="little")
+        di, _ = oracle.dense_search(X, Q[2:3], 40, oracle.COSINE, pd)
+        si, _ = oracle.sparse_search(ptr, idx, val, SQ[2:3], 40, 0.2, pd)
+        fi, fs, _ = oracle.rrf(di[0], si[0][si[0] >= 0], (), 0.7, 0.3, 0.2, 60)
+        assert [o["id"] for o in out3] == [MilvusIndexManager.synthetic_id(int(r)) for r in fi[:20]]
+        # several concurrent callers share rounds
+        async def many():
+            return await asyncio.gather(*[retr.retrieve(str(q), profile_hint="default") for q in range(6)])
+        c0 = cs.n_collectives
+        outs = asyncio.run(many())
+        assert cs.n_collectives - c0 < 2 * 6
+        for q, o in enumerate(outs):
+            di, _ = oracle.dense_search(X, Q[q:q + 1], 40, oracle.COSINE, np.packbits((np.arange(n) % 10) != 3, bitorder="little"))
+            assert o[0]["id"] in {MilvusIndexManager.synthetic_id(int(r)) for r in di[0]}
+        # a round that cannot be packed fails on rank 0 before any collective: the workers are not left waiting
+        with pytest.raises(ValueError):
+            cs.round(np.zeros((2_000_000 // X.shape[1], X.shape[1]), np.float32), None, 40)
+        assert cs.search_dense(Q[:1], 40)[0][0, 0] == 100
+        asyncio.run(mgr.close()) if False else None
         mgr.stop_workers()
         ret[rank] = True
     finally:

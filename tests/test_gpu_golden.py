@@ -100,9 +100,10 @@ def test_g5_retrieve_on_device_fp32_matches_reference(gpu, long_timeout):
 
 def test_g5_retrieve_on_device_fp16_reports_rank_flips(gpu, long_timeout):
     """The same corpus rounded to fp16 rows (the storage type of configs 3-5).  Rounding the corpus perturbs
-    cosine scores by ~1e-4 relative, so a rank flip against the fp32 reference is possible where two scores
-    are closer than that; every flip is REPORTED with its fp32 score gap and must be explained by a gap
-    below 2e-3, and at least 12 of the 16 runs must be identical outright."""
+    cosine scores by ~1e-4 relative, so a rank flip against the fp32 reference would be possible where two scores
+    are closer than that — on this corpus there is none: all 16 runs return the reference's ids and fused scores (the
+    kernels are deterministic, so this is a property of the fixture, asserted as such; a flip, should a change ever
+    produce one, is reported with its fp32 score gap)."""
     g, X, csr, Q, SQ = g5_data.inputs()
     Xn = X / np.linalg.norm(X, axis=1, keepdims=True)
     identical, flips = 0, []
@@ -124,8 +125,7 @@ def test_g5_retrieve_on_device_fp16_reports_rank_flips(gpu, long_timeout):
         finally:
             asyncio.run(mgr.close())
     print(f"g5 fp16: {identical}/16 runs identical to the fp32 reference; flips (sparse, query, pos, got, want, fp32 gap): {flips}")
-    assert identical >= 12, flips
-    assert all(f[5] < 2e-3 for f in flips), flips
+    assert identical == 16 and not flips, flips
 
 
 # --------------------------------------------------------------------------- g1 / g2
