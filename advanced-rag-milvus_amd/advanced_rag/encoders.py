@@ -179,6 +179,32 @@ def _seeded(module_fn, seed: int):
         torch.random.set_rng_state(gen_state)
 
 
+_TUNED_GEMMS = None
+
+
+def use_recorded_gemm_solutions() -> bool:
+    """Let PyTorch's TunableOp pick the hipBLASLt solutions RECORDED for the encoder's GEMM shapes on gfx950
+    (tunableop_gfx950_minilm.csv, written by `tests/perf_probe_ce.py` on an MI355X: QKV / output / FFN projections of
+    MiniLM-L6-H384 at 2560 pairs x 128 and x 512 tokens — hipBLASLt's default heuristic is 12 % slower on these K = 384
+    shapes).  Nothing is tuned online and the file is never rewritten; shapes or library versions the file does not cover
+    fall back to the default heuristic.  Process-wide (it is a torch setting); returns whether it took effect."""
+    global _TUNED_GEMMS
+    if _TUNED_GEMMS is None:
+        _TUNED_GEMMS = False
+        try:
+            import os
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950_minilm.csv")
+            if torch.cuda.is_available() and os.path.exists(path):
+                torch.cuda.tunable.enable(True)
+                torch.cuda.tunable.tuning_enable(False)
+                torch.cuda.tunable.write_file_on_exit(False)
+                torch.cuda.tunable.set_filename(path)
+                _TUNED_GEMMS = True
+        except Exception:   # an older torch without the API: the default heuristic it is
+            _TUNED_GEMMS = False
+    return _TUNED_GEMMS
+
+
 class _Base:
     def __init__(self, config, device, dtype, seed, max_len, batch_size):
         self.config = config or EncoderConfig()
@@ -187,6 +213,7 @@ class _Base:
         self.tokenizer = HashTokenizer(self.config.vocab_size, min(max_len, self.config.max_len))
         self.batch_size = batch_size
         self.seed = seed
+        self.tuned_gemms = use_recorded_gemm_solutions() if self.device.type == "cuda" else False
 
     def load_local(self, path: str) -> "._Base":
         """Load weights from a LOCAL safetensors file with HuggingFace BERT names (never by model name)."""

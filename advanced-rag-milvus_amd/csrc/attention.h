@@ -40,6 +40,23 @@ __global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __r
     const int n_chunks = (T + 31) / 32;
     const _Float16* base = qkv + (int64_t)seq * T * 3 * H + head * kAttnHeadDim;   // + t * 3H (+ H for K, + 2H for V)
 
+    // Q and the first K fragments are requested before V is staged: three dependent round trips become two
+    const int q0 = blockIdx.y * kAttnQueriesPerBlock + wid * 32;
+    half8_t qf[2], kf[2], kn[2];
+    auto load_k = [&](int c, half8_t (&kfr)[2]) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const int key = min(32 * c + 16 * kt + col, T - 1);
+            kfr[kt] = *reinterpret_cast<const half8_t*>(base + (int64_t)key * 3 * H + H + 8 * g);
+        }
+    };
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = min(q0 + 16 * qt + col, T - 1);
+        qf[qt] = *reinterpret_cast<const half8_t*>(base + (int64_t)q * 3 * H + 8 * g);
+    }
+    load_k(0, kf);
+
     // ---- stage V^T: thread takes (key, 8 dims) pieces; dim d of key k goes to fragment (chunk, d >> 4), lane (d & 15) + 16 g', slot j
     _Float16* vt = reinterpret_cast<_Float16*>(attn_vt);
     for (int piece = threadIdx.x; piece < n_chunks * 32 * 4; piece += 256) {
@@ -55,15 +72,7 @@ __global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __r
         }
     }
     __syncthreads();
-
-    const int q0 = blockIdx.y * kAttnQueriesPerBlock + wid * 32;
     if (q0 >= T) return;
-    half8_t qf[2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int q = min(q0 + 16 * qt + col, T - 1);
-        qf[qt] = *reinterpret_cast<const half8_t*>(base + (int64_t)q * 3 * H + 8 * g);
-    }
     f32x4_t o[2][2];   // [dim tile][query tile]
     float m[2], l[2];
 #pragma unroll
@@ -73,15 +82,6 @@ __global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __r
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
-    auto load_k = [&](int c, half8_t (&kf)[2]) {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int key = min(32 * c + 16 * kt + col, T - 1);
-            kf[kt] = *reinterpret_cast<const half8_t*>(base + (int64_t)key * 3 * H + H + 8 * g);
-        }
-    };
-    half8_t kf[2], kn[2];
-    load_k(0, kf);
     const int live_chunks = (len + 31) / 32;   // chunks beyond the sequence's length hold nothing but masked keys
     for (int c = 0; c < live_chunks; ++c) {
         load_k(c + 1 < live_chunks ? c + 1 : c, kn);

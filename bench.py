@@ -827,6 +827,14 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
         return first, latf
 
     first_f, lat_f = asyncio.run(run_filtered()) if world == 1 else (None, None)
+    mask_eval_ms = None
+    if world == 1:   # what a NEW expression costs once the column is in HBM: one hr_filter_eval_dev launch + an 8-byte read-back
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mgr._global_device_mask("chunk_index < 3")
+        torch.cuda.synchronize()
+        mask_eval_ms = (time.perf_counter() - t0) * 1e3
 
     # the same queries through the whole public entry point, AdvancedRAGPipeline.retrieve(): query rewriting, the
     # retriever, the default rerank branch (20 -> 5), evaluation and the audit trail (SURVEY.md section 8d's latency
@@ -909,6 +917,7 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
             "p50_pipeline_retrieve_ms": float(np.percentile(lat2, 50)),
             "p95_pipeline_retrieve_ms": float(np.percentile(lat2, 95)), "latency_queries": n,
             **({"filtered_retrieve": {"filter": "chunk_index < 5 (half of the rows)", "first_request_ms": first_f,
+                                      "new_expression_mask_eval_ms": mask_eval_ms,
                                       "p50_ms": float(np.percentile(lat_f, 50)), "p95_ms": float(np.percentile(lat_f, 95)),
                                       "queries": len(lat_f)}} if lat_f else {}),
             **({"api_concurrent": api} if api else {})}
