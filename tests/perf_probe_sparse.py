@@ -7,22 +7,25 @@ sys.path.insert(0, "advanced-rag-milvus_amd")
 sys.path.insert(0, ".")
 from advanced_rag import _native as nat
 from advanced_rag.engine import pack_sparse_queries
-from bench import sparse_block, SPARSE_DIM, SPARSE_NNZ
+from bench import sparse_block, sparse_block_zipf, zipf_queries, SPARSE_DIM, SPARSE_NNZ
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_500_000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+ZIPF = len(sys.argv) > 3 and sys.argv[3] == "zipf"   # Zipf(1.1) postings + 20-term queries (bench.py --sparse-dist zipf)
 dev = torch.device("cuda:0")
 h = nat.ShardHandle(64, nat.HR_F16, nat.HR_METRIC_COSINE, SPARSE_DIM)
 blk = 250_000
 for b in range(N // blk):
     h.add_dense(np.zeros((blk, 64), np.float16) + 1)
-    h.add_sparse(*sparse_block(b, blk))
+    h.add_sparse(*(sparse_block_zipf(b, blk) if ZIPF else sparse_block(b, blk)))
 h.finalize()
 L = nat.load_library()
 trace = getattr(L, "hr_debug_trace", None)
 rng = np.random.default_rng(3)
 _, idx, val = sparse_block(0, B, seed=77)
 sq = [(idx[i * SPARSE_NNZ:(i + 1) * SPARSE_NNZ], val[i * SPARSE_NNZ:(i + 1) * SPARSE_NNZ]) for i in range(B)]
+if ZIPF:
+    sq = zipf_queries(rng, B)
 ptr, qi, qv, mx = pack_sparse_queries(sq, 0.2)
 d_ptr, d_i, d_v = (torch.from_numpy(a).to(dev) for a in (ptr, qi, qv))
 ids = torch.empty((B, 40), dtype=torch.int64, device=dev)
