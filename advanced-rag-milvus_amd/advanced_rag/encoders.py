@@ -193,12 +193,16 @@ def use_recorded_gemm_solutions() -> bool:
         _TUNED_GEMMS = False
         try:
             import os
+            import shutil
+            import tempfile
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950_minilm.csv")
             if torch.cuda.is_available() and os.path.exists(path):
+                # TunableOp may rewrite its results file when the process ends: it gets a private copy
+                work = os.path.join(tempfile.gettempdir(), f"hbmrag_tunableop_{os.getpid()}.csv")
+                shutil.copyfile(path, work)
                 torch.cuda.tunable.enable(True)
                 torch.cuda.tunable.tuning_enable(False)
-                torch.cuda.tunable.write_file_on_exit(False)
-                torch.cuda.tunable.set_filename(path)
+                torch.cuda.tunable.set_filename(work)
                 _TUNED_GEMMS = True
         except Exception:   # an older torch without the API: the default heuristic it is
             _TUNED_GEMMS = False
