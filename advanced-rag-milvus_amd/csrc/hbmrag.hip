@@ -143,8 +143,6 @@ struct hr_index {
     int64_t n_sparse = 0, n_csr = 0, nnz_csr = 0, n_sparse_built = 0;
     float max_sparse_abs = 0.f;  // max |doc weight|: bounds the scan's fixed-point range
     DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post;  // post: packed (fp16 weight | u16 accumulator slot)
-    DevBuf rt_tm;              // term-major (run start, run length) pairs: what the scan reads (sparse.h)
-    int64_t tm_cap = 0;        // its row stride, in ranges
     DevBuf idle_post;  // 64 x 4 idle postings: what scan lanes with nothing to fetch read (sparse.h)
     int64_t n_ranges = 0;
 
@@ -781,6 +779,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     HIP_TRY(h, ws->crow.ensure((size_t)B * C * GR * sizeof(int32_t)));
     HIP_TRY(h, ws->qscale.ensure((size_t)B * sizeof(float)));
     HIP_TRY(h, ws->qeps.ensure((size_t)B * sizeof(float)));
+    const int64_t V1 = h->sparse_dim + 1;
     const int stride = (int)round_up(std::max(max_q_nnz, 1), 64);  // fixed-stride query layout for the scan
     if (phases & PHASE_PREP) {
         HIP_TRY(h, ws->pq_n.ensure((size_t)B * 4));
@@ -796,7 +795,7 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         const int rpb = sparse_ranges_per_block(h, B);
         const unsigned chunks = (unsigned)((h->n_ranges + rpb - 1) / rpb);
         hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)B, chunks), dim3(kScanThreads), 0, s,
-                           h->rt_tm.as<u32x2_t>(), h->tm_cap, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
+                           h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
                            ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
                            ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, rpb,
                            h->idle_post.as<uint32_t>(), ws->gmax.as<float>());
@@ -1093,25 +1092,6 @@ int build_sparse(hr_index* h) {
                        h->rt_off.as<unsigned int>(), tmp.cursor.as<unsigned int>(), V1, r_d, n_ranges,
                        h->range_base.as<int64_t>(), h->post.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());
-    // term-major copy of the run bounds for the scan: the dirty ranges' columns, or everything when the rows grow
-    {
-        int64_t t_lo = r_d;
-        if (n_ranges > h->tm_cap) {
-            const int64_t cap = round_up(std::max<int64_t>(n_ranges + n_ranges / 2, 16), 16);
-            DevBuf grown;
-            HIP_TRY(h, grown.ensure((size_t)h->sparse_dim * cap * 8));
-            HIP_TRY(h, hipMemsetAsync(grown.p, 0, (size_t)h->sparse_dim * cap * 8, s));
-            HIP_TRY(h, hipStreamSynchronize(s));
-            h->rt_tm.release();
-            h->rt_tm = grown;
-            h->tm_cap = cap;
-            t_lo = 0;   // the new rows start empty: every range's column is written again
-        }
-        const int64_t cells = (n_ranges - t_lo) * h->sparse_dim;
-        hipLaunchKernelGGL(sparse_transpose_bounds_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s,
-                           h->rt_off.as<unsigned int>(), V1, t_lo, n_ranges, h->tm_cap, h->rt_tm.as<u32x2_t>());
-        HIP_TRY(h, hipGetLastError());
-    }
     HIP_TRY(h, hipStreamSynchronize(s));
     h->n_ranges = n_ranges;
     h->n_sparse_built = n;
@@ -1191,7 +1171,7 @@ void hr_destroy(hr_index* h) {
         for (auto& sp : h->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
         for (hipEvent_t e : h->event_pool) (void)hipEventDestroy(e);
         for (DevBuf* b : {&h->tiles, &h->scale, &h->norm2, &h->max_norm, &h->stage, &h->s_indptr, &h->s_idx, &h->s_val,
-                          &h->rt_off, &h->range_base, &h->post, &h->idle_post, &h->rt_tm})
+                          &h->rt_off, &h->range_base, &h->post, &h->idle_post})
             b->release();
         if (h->ingest_stream) (void)hipStreamDestroy(h->ingest_stream);
     }
@@ -1488,7 +1468,7 @@ int64_t hr_device_bytes(const hr_index* h) {
     if (!h) return 0;
     size_t t = 0;
     for (const DevBuf* b : {&h->tiles, &h->scale, &h->norm2, &h->s_indptr, &h->s_idx, &h->s_val, &h->rt_off,
-                            &h->range_base, &h->post, &h->rt_tm})
+                            &h->range_base, &h->post})
         t += b->cap;
     return (int64_t)t;
 }

@@ -64,23 +64,6 @@ __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int*
     }
 }
 
-// TERM-major copy of the run bounds for the scan: rt_tm[t][range] = (first posting of term t's run inside the range's
-// block, padded run length).  A scan block walks up to 16 CONSECUTIVE ranges of one query: the bounds of one query
-// term over those ranges are 16 x 8 = 128 contiguous bytes — one line per term per block — where the range-major
-// table above costs a 64- to 128-byte fetch for every (term, range) pair (two 4-byte reads out of a 40 KB row): at
-// 80 terms x 164 postings per (term, range) that was the scan's whole fetch overshoot (1.155x the algorithmic bytes;
-// profiles/r2_pmc_traffic.json).  `cap` = row stride in ranges (capacity; a multiple of 16).
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-__global__ void sparse_transpose_bounds_kernel(const unsigned int* __restrict__ rt_off, int64_t V1, int64_t range0,
-                                               int64_t n_ranges, int64_t cap, u32x2_t* __restrict__ rt_tm) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (range - range0, term), term fastest
-    const int64_t V = V1 - 1;
-    if (i >= (n_ranges - range0) * V) return;
-    const int64_t rel = i / V, t = i - rel * V, range = range0 + rel;
-    const unsigned int lo = rt_off[range * V1 + t], hi = rt_off[range * V1 + t + 1];
-    rt_tm[t * cap + range] = (u32x2_t){lo, hi - lo};
-}
-
 // A posting is 4 bytes: fp16 weight (high half) | uint16 accumulator slot of the doc inside its range.
 // The scan is only the candidate generator (the refine recomputes from the fp32
 // CSR), so the weight may be rounded; a positive weight never rounds to zero, so
@@ -246,7 +229,7 @@ struct ScanTab {
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load at 4-byte alignment
 
 __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_kernel(
-    const u32x2_t* __restrict__ rt_tm, int64_t tm_cap, const int64_t* __restrict__ range_base,
+    const unsigned int* __restrict__ rt_off, int64_t V1, const int64_t* __restrict__ range_base,
     const uint32_t* __restrict__ post, const int32_t* __restrict__ pq_n, const int32_t* __restrict__ pq_idx,
     const float* __restrict__ pq_w, int stride, const float* __restrict__ q_scale,
     const uint8_t* __restrict__ rowmask, int64_t n_docs, int64_t n_groups, int group_docs, int64_t n_ranges,
@@ -289,12 +272,11 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
     auto p_issue = [&](int g, unsigned (&lo)[4], unsigned (&hi)[4], float (&w)[4], unsigned long long& base) {
         const int range = g / n_chunks, chunk = g - range * n_chunks;
         if (n_chunks > 1) p_terms(chunk, w);
-        const u32x2_t* col = rt_tm + (r0 + range);   // entry (term, range) = col[term * tm_cap]
+        const unsigned int* offs = rt_off + (r0 + range) * V1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u32x2_t e = col[(int64_t)t4[j] * tm_cap];
-            lo[j] = e.x;
-            hi[j] = e.x + e.y;
+            lo[j] = offs[t4[j]];
+            hi[j] = offs[t4[j] + 1];
         }
         base = (unsigned long long)range_base[r0 + range];
     };
