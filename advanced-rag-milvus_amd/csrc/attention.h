@@ -56,6 +56,13 @@ __global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __r
         qf[qt] = *reinterpret_cast<const half8_t*>(base + (int64_t)q * 3 * H + 8 * g);
     }
     load_k(0, kf);
+    // the softmax scale (x log2 e) goes into Q once — 8 multiplies per query tile instead of one per score; the
+    // product is rounded to fp16 like Q itself (|scale| < 1: no overflow), well inside the kernel's fp16 tolerance
+    const _Float16 qs = (_Float16)scale_log2e;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[qt][i] *= qs;
 
     // ---- stage V^T: thread takes (key, 8 dims) pieces; dim d of key k goes to fragment (chunk, d >> 4), lane (d & 15) + 16 g', slot j
     _Float16* vt = reinterpret_cast<_Float16*>(attn_vt);
@@ -91,37 +98,40 @@ __global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __r
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
                 s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf[qt], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // keys at or beyond the length exist only in the sequence's last live chunk: the mask costs nothing elsewhere
+        if (32 * c + 32 > len) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (32 * c + 16 * kt + 4 * g + r >= len) s[kt][qt][r] = -__builtin_inff();
+        }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = -__builtin_inff();
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = 32 * c + 16 * kt + 4 * g + r;
-                    const float v = key < len ? s[kt][qt][r] * scale_log2e : -__builtin_inff();
-                    s[kt][qt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+            float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                             fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+            // key 0 is always valid (length >= 1), so the running maximum is finite from the first chunk on
             const float m_new = fmaxf(m[qt], wave_col_max(mx));
-            const float alpha = m_new == -__builtin_inff() ? 1.f : exp2f(m[qt] - m_new);
+            const float alpha = exp2f(m[qt] - m_new);   // first chunk: exp2(-inf) = 0 times a zero accumulator
             m[qt] = m_new;
-            float sum = 0.f;
-            half8_t p;
+            float e[8];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = m_new == -__builtin_inff() ? 0.f : exp2f(s[kt][qt][r] - m_new);
-                    sum += e;
-                    p[4 * kt + r] = (_Float16)e;
-                }
+                for (int r = 0; r < 4; ++r) e[4 * kt + r] = exp2f(s[kt][qt][r] - m_new);
+            const float sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+            typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+            union { half8_t v; fp16x2_t h2[4]; } p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p.h2[i] = __builtin_amdgcn_cvt_pkrtz(e[2 * i], e[2 * i + 1]);
             l[qt] = l[qt] * alpha + sum;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
-                o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_vt[(c * 2 + dt) * 64 + lane], p, o[dt][qt], 0, 0, 0);
+                o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_vt[(c * 2 + dt) * 64 + lane], p.v, o[dt][qt], 0, 0, 0);
             }
         }
         kf[0] = kn[0];
