@@ -132,112 +132,13 @@ struct Mfma<float> {
     }
 };
 
-// ---- per-group auxiliary word (round 3): which row attained the group's maximum, and an upper bound of the SECOND
-// largest approximate score of the group.  With it the finishing kernel refines ONE row per candidate group first and
-// the other rows only of the groups whose runner-up could still reach the top-k' (finish.h) — a tenth of the candidate
-// rows.  Layout: bits 31..6 = the runner-up as fp32 with its low 6 mantissa bits rounded toward +inf (2^-17 relative:
-// far below the scan's own error bound), bits 5..0 = index of the best row inside the group (< 64).
-struct Top2 {
-    float m1, m2;
-    int i1;
-};
-__device__ inline void top2_push(Top2& t, float v, int idx) {   // idx ascending over calls: ties keep the lower index
-    t.m2 = fmaxf(t.m2, fminf(t.m1, v));
-    t.i1 = v > t.m1 ? idx : t.i1;
-    t.m1 = fmaxf(t.m1, v);
-}
-__device__ inline void top2_merge_xor(Top2& t, int mask) {
-    const float om1 = __shfl_xor(t.m1, mask), om2 = __shfl_xor(t.m2, mask);
-    const int oi = __shfl_xor(t.i1, mask);
-    const bool take = om1 > t.m1 || (om1 == t.m1 && oi < t.i1);
-    t.m2 = fmaxf(fmaxf(t.m2, om2), fminf(t.m1, om1));
-    t.i1 = take ? oi : t.i1;
-    t.m1 = fmaxf(t.m1, om1);
-}
-__host__ __device__ inline uint32_t pack_group_aux(float m2, int i1) {
-    union { float f; uint32_t u; } c;
-    c.f = m2;
-    const uint32_t b = (c.u & 0x80000000u) ? (c.u & ~63u) : ((c.u + 63u) & ~63u);   // toward +inf; -inf stays -inf
-    return b | (uint32_t)(i1 & 63);
-}
-__host__ __device__ inline float group_aux_runner_up(uint32_t aux) {
-    union { float f; uint32_t u; } c;
-    c.u = aux & ~63u;
-    return c.f;
-}
-
 // PF = depth of the per-wave register prefetch ring (k-steps in flight); KT is
 // padded to a multiple of PF at hr_create so ring slots stay compile-time.
-// Epilogue of one row block for G query groups (shared by the <= 64-query and the 128-query scans): scale, mask, and
-// either (NRB = 1: the row block IS a candidate group) reduce over the four lane quads and write the group maximum
-// (+ auxiliary word), or (NRB = 4) fold into the super-group's running values in m / t2.
-template <int G, int NRB, bool AUX>
-__device__ inline void scan_epilogue(const f32x4_t (&acc)[G], const f32x4_t& sc, const float (&ok)[4], int rb_in_super,
-                                     int quad, int lane, int nq, float* __restrict__ gmax, uint32_t* __restrict__ gaux,
-                                     int64_t gmax_stride, int64_t group_index, float (&m)[G], Top2 (&t2)[G]) {
-    const float NEG_INF = -__builtin_inff();
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float x = acc[g][r] * sc[r];
-            v[r] = (ok[r] != 0.f) ? x : NEG_INF;
-        }
-        if (!AUX) {
-            float mr = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-            if (NRB == 1) {  // this row block is a candidate group of its own
-                mr = fmaxf(mr, __shfl_xor(mr, 16));
-                mr = fmaxf(mr, __shfl_xor(mr, 32));
-                if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * gmax_stride + group_index] = mr;
-            } else {
-                m[g] = fmaxf(m[g], mr);
-            }
-        } else if (NRB == 1) {
-            Top2 t{NEG_INF, NEG_INF, 0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) top2_push(t, v[r], quad * 4 + r);
-            top2_merge_xor(t, 16);
-            top2_merge_xor(t, 32);
-            if (lane < 16 && 16 * g + lane < nq) {
-                const int64_t o = (int64_t)(16 * g + lane) * gmax_stride + group_index;
-                gmax[o] = t.m1;
-                gaux[o] = pack_group_aux(t.m2, t.i1);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) top2_push(t2[g], v[r], rb_in_super * kRowsPerBlock + quad * 4 + r);
-        }
-    }
-}
-template <int G, bool AUX>
-__device__ inline void scan_epilogue_super(float (&m)[G], Top2 (&t2)[G], int lane, int nq, float* __restrict__ gmax,
-                                           uint32_t* __restrict__ gaux, int64_t gmax_stride, int64_t group) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (!AUX) {
-            float v = m[g];
-            v = fmaxf(v, __shfl_xor(v, 16));
-            v = fmaxf(v, __shfl_xor(v, 32));
-            if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * gmax_stride + group] = v;
-        } else {
-            Top2 t = t2[g];
-            top2_merge_xor(t, 16);
-            top2_merge_xor(t, 32);
-            if (lane < 16 && 16 * g + lane < nq) {
-                const int64_t o = (int64_t)(16 * g + lane) * gmax_stride + group;
-                gmax[o] = t.m1;
-                gaux[o] = pack_group_aux(t.m2, t.i1);
-            }
-        }
-    }
-}
-
-template <typename STORE, int G, int RS, int PF, int NRB, bool AUX>
+template <typename STORE, int G, int RS, int PF, int NRB>
 __global__ __launch_bounds__(512) void dense_scan_kernel(
     const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
-    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, uint32_t* __restrict__ gaux, int nq, int KT,
-    int64_t n_rows, int64_t n_super) {
+    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int KT, int64_t n_rows,
+    int64_t n_super) {
     // NRB = row blocks per candidate group: 4 (64-row groups) or 1 (16-row groups).
     // `group` below walks SUPER-groups of 4 row blocks either way; gmax is [nq][n_super*4/NRB].
     static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
@@ -281,12 +182,8 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
 
     for (int64_t group = wave; group < n_groups; group += total_waves) {
         float m[G];
-        Top2 t2[G];   // 64-row groups with the auxiliary word: best / runner-up / best row across the four row blocks
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            m[g] = NEG_INF;
-            t2[g] = Top2{NEG_INF, NEG_INF, 0};
-        }
+        for (int g = 0; g < G; ++g) m[g] = NEG_INF;
         const bool tail = (group + 1) * kSuperRows > n_rows || rowmask != nullptr;
 
 #pragma unroll 1
@@ -325,11 +222,35 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
                         ok[r] = v ? 1.f : 0.f;
                     }
                 }
-                scan_epilogue<G, NRB, AUX>(acc[s], sc, ok, (pair * RS + s), quad, lane, nq, gmax, gaux, gmax_stride,
-                                           group * kRowBlocksPerSuper + pair * RS + s, m, t2);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    float mr = NEG_INF;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[s][g][r] * sc[r];
+                        v = (ok[r] != 0.f) ? v : NEG_INF;
+                        mr = fmaxf(mr, v);
+                    }
+                    if (NRB == 1) {  // this row block is a candidate group of its own
+                        mr = fmaxf(mr, __shfl_xor(mr, 16));
+                        mr = fmaxf(mr, __shfl_xor(mr, 32));
+                        if (lane < 16 && 16 * g + lane < nq)
+                            gmax[(int64_t)(16 * g + lane) * gmax_stride + group * kRowBlocksPerSuper + pair * RS + s] = mr;
+                    } else {
+                        m[g] = fmaxf(m[g], mr);
+                    }
+                }
             }
         }
-        if (NRB != 1) scan_epilogue_super<G, AUX>(m, t2, lane, nq, gmax, gaux, gmax_stride, group);
+        if (NRB != 1) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float v = m[g];
+                v = fmaxf(v, __shfl_xor(v, 16));
+                v = fmaxf(v, __shfl_xor(v, 32));
+                if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * gmax_stride + group] = v;
+            }
+        }
     }
 }
 
@@ -346,11 +267,11 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
 // L2: L2 : HBM traffic = 1 : 1.  MFMA work per corpus KiB is GQ x 16 cycles per
 // SIMD (GQ = 16: 64 cycles per KiB per CU against ~100 cycles per KiB of HBM
 // supply), so the pass stays HBM-bound.
-template <typename STORE, int GQ, int NRB, bool AUX>
+template <typename STORE, int GQ, int NRB>
 __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
     const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
-    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, uint32_t* __restrict__ gaux, int nq, int KT,
-    int64_t n_rows, int64_t n_super) {
+    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int KT, int64_t n_rows,
+    int64_t n_super) {
     constexpr int RS = 2, BKT = 2, PF = 4;  // query chunk = 2 k-steps (16 staging registers), corpus ring = 4 k-steps
     constexpr int kPairs = kRowBlocksPerSuper / RS;
     constexpr int kFrags = GQ * BKT;           // 1 KiB query fragments per k-chunk
@@ -405,12 +326,8 @@ __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
         const int64_t group = round * total_waves + wave;
         const bool live = group < n_super;
         float m[GQ];
-        Top2 t2[GQ];
 #pragma unroll
-        for (int g = 0; g < GQ; ++g) {
-            m[g] = NEG_INF;
-            t2[g] = Top2{NEG_INF, NEG_INF, 0};
-        }
+        for (int g = 0; g < GQ; ++g) m[g] = NEG_INF;
         const bool tail = live && ((group + 1) * kSuperRows > n_rows || rowmask != nullptr);
 #pragma unroll 1
         for (int pair = 0; pair < kPairs; ++pair) {
@@ -469,12 +386,36 @@ __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
                             ok[r] = v ? 1.f : 0.f;
                         }
                     }
-                    scan_epilogue<GQ, NRB, AUX>(acc[s], sc, ok, pair * RS + s, quad, lane, nq, gmax, gaux, gmax_stride,
-                                                group * kRowBlocksPerSuper + pair * RS + s, m, t2);
+#pragma unroll
+                    for (int g = 0; g < GQ; ++g) {
+                        float mr = NEG_INF;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[s][g][r] * sc[r];
+                            v = (ok[r] != 0.f) ? v : NEG_INF;
+                            mr = fmaxf(mr, v);
+                        }
+                        if (NRB == 1) {
+                            mr = fmaxf(mr, __shfl_xor(mr, 16));
+                            mr = fmaxf(mr, __shfl_xor(mr, 32));
+                            if (lane < 16 && 16 * g + lane < nq)
+                                gmax[(int64_t)(16 * g + lane) * gmax_stride + group * kRowBlocksPerSuper + pair * RS + s] = mr;
+                        } else {
+                            m[g] = fmaxf(m[g], mr);
+                        }
+                    }
                 }
             }
         }
-        if (NRB != 1 && live) scan_epilogue_super<GQ, AUX>(m, t2, lane, nq, gmax, gaux, gmax_stride, group);
+        if (NRB != 1 && live) {
+#pragma unroll
+            for (int g = 0; g < GQ; ++g) {
+                float v = m[g];
+                v = fmaxf(v, __shfl_xor(v, 16));
+                v = fmaxf(v, __shfl_xor(v, 32));
+                if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * gmax_stride + group] = v;
+            }
+        }
     }
 }
 

@@ -33,7 +33,6 @@ struct FinishMod {
     const float* q;
     const double* qn2;
     const double* norm2;
-    const uint32_t* gaux;      // [B][n_groups] auxiliary words of the scan (best row + runner-up), or null
     // sparse
     const int64_t* indptr;
     const int32_t* idx;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
         for (int k = tid; k < a.dim; k += kFinishThreads) qq[k] = a.q[(int64_t)q * a.dim + k];
         __syncthreads();
         const double qn2 = a.qn2[q];
-        auto refine = [&](int slot) {
+        for (int slot = tid; slot < n_slots; slot += kFinishThreads) {
             float sc = 0.f;
             int32_t row = -1;
             const bool ok = a.dtype == HR_F16
@@ -140,39 +139,6 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
                                 : refine_dense_slot<float>(a.tiles, a.KT, a.dim, qq, qn2, a.norm2, a.rowmask, s_cand,
                                                            a.group_rows, a.n_rows, a.cosine, slot, &sc, &row);
             s_key[slot] = ok ? rank_key(sc, (uint32_t)row) : 0ull;
-        };
-        if (a.gaux == nullptr) {
-            for (int slot = tid; slot < n_slots; slot += kFinishThreads) refine(slot);
-        } else {
-            // Two rounds.  1: the best row of every candidate group (the scan recorded which one) — C rows instead of
-            // C x group_rows.  2: t = the K-th best canonical score so far bounds the final K-th from below, and every
-            // row that was not refined scores at most its group's runner-up (+ the scan's error bound) in the canonical
-            // arithmetic: only the groups whose runner-up could still reach t are refined in full.  On a corpus without
-            // near-duplicates that is a handful of groups; the lists are the ones the full refine gives (the skipped
-            // rows provably rank below the K-th), and the exactness flag is computed exactly as before.
-            const int C = a.sel.C, GR = a.group_rows;
-            uint32_t* s_aux = reinterpret_cast<uint32_t*>(sel_bucket);   // the bucket list is no longer needed (C <= 256 words)
-            for (int slot = tid; slot < n_slots; slot += kFinishThreads) s_key[slot] = 0ull;
-            for (int c = tid; c < C; c += kFinishThreads) {
-                const int32_t group = s_cand[c];
-                s_aux[c] = group >= 0 ? a.gaux[(int64_t)q * a.sel.n_groups + group] : 0xFF800000u;   // runner-up -inf, row 0
-            }
-            __syncthreads();
-            for (int c = tid; c < C; c += kFinishThreads) refine(c * GR + (int)(s_aux[c] & 63u));
-            __syncthreads();
-            const int Ke = a.topk.K < n_slots ? a.topk.K : n_slots;
-            const uint64_t kth = block_kth_largest([&](int64_t i) -> uint64_t { return s_key[i]; }, n_slots, Ke, sh);
-            // the bound check of select_topk_block, with the group's runner-up in the place of a_cut
-            double t = kth ? (double)key_score(kth) : -(double)__builtin_inff();
-            if (kth && a.topk.norm_mode == 1) t = qn2 > 0.0 ? t / sqrt(qn2) : 0.0;
-            for (int slot = tid; slot < n_slots; slot += kFinishThreads) {
-                const int c = slot / GR;
-                const uint32_t aux = s_aux[c];
-                if ((slot - c * GR) == (int)(aux & 63u)) continue;          // refined in round 1
-                const double ru = (double)group_aux_runner_up(aux);
-                const double bound = ru + (double)a.topk.eps_abs + (double)a.topk.eps_rel * fabs(ru);
-                if (!(t > bound)) refine(slot);                              // also when fewer than K rows are in (t = -inf)
-            }
         }
     } else {
         unsigned int* s_filter = reinterpret_cast<unsigned int*>(s_bmax);  // the bucket maxima are no longer needed

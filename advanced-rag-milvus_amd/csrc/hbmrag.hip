@@ -89,13 +89,12 @@ struct Workspace {
     hipStream_t side = nullptr;    // side stream + events of hr_search_hybrid_dev
     hipEvent_t ev_scan = nullptr, ev_side = nullptr;
     struct Workspace* sparse_ws = nullptr;  // private buffers of the sparse chain when it runs concurrently
-    DevBuf qfrag, qn2, gmax, gaux, bmax, cand, acut, cscore, crow, flags, qscale, qeps, pq_n, pq_idx, pq_w;
-    bool aux_valid = false;        // the dense scan of the batch in this workspace wrote the groups' auxiliary words (gaux)
+    DevBuf qfrag, qn2, gmax, bmax, cand, acut, cscore, crow, flags, qscale, qeps, pq_n, pq_idx, pq_w;
     DevBuf d_q, d_ids, d_scores, d_mask;          // host-form staging
     DevBuf d_qptr, d_qidx, d_qval;                // sparse query staging
     DevBuf f_ids, f_out_ids, f_out_scores, f_out_meth, f_n;  // hr_fuse_rrf staging
     void release() {
-        for (DevBuf* b : {&qfrag, &qn2, &gmax, &gaux, &bmax, &qscale, &qeps, &pq_n, &pq_idx, &pq_w, &cand, &acut, &cscore, &crow, &flags, &d_q, &d_ids, &d_scores,
+        for (DevBuf* b : {&qfrag, &qn2, &gmax, &bmax, &qscale, &qeps, &pq_n, &pq_idx, &pq_w, &cand, &acut, &cscore, &crow, &flags, &d_q, &d_ids, &d_scores,
                           &d_mask, &d_qptr, &d_qidx, &d_qval, &f_ids, &f_out_ids, &f_out_scores, &f_out_meth, &f_n})
             b->release();
         if (stream) (void)hipStreamDestroy(stream);
@@ -333,11 +332,11 @@ int group_rows_for(const hr_index* h, int64_t n) {
 }
 
 // ---- dense launch helpers ----------------------------------------------------
-template <typename STORE, int G, int NRB, bool AUX>
-hipError_t launch_scan_x(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
-                         uint32_t* gaux, int nq, int64_t n_groups) {
+template <typename STORE, int G, int NRB>
+hipError_t launch_scan(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                       int nq, int64_t n_groups) {
     constexpr int RS = 2, PF = 4;
-    auto kern = dense_scan_kernel<STORE, G, RS, PF, NRB, AUX>;
+    auto kern = dense_scan_kernel<STORE, G, RS, PF, NRB>;
     const size_t lds = (size_t)G * h->KT * 1024;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -356,62 +355,49 @@ hipError_t launch_scan_x(const hr_index* h, hipStream_t s, const chunk_t* qfrag,
                                        (int64_t)scan_cus(h) * per_cu);
     blocks = std::max<int64_t>(blocks, 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds, s, h->tiles.as<chunk_t>(), qfrag,
-                       h->scale.as<float>(), mask, gmax, gaux, nq, h->KT, h->n_rows, n_groups);
+                       h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_groups);
     return hipGetLastError();
-}
-
-template <typename STORE, int G, int NRB>
-hipError_t launch_scan(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
-                       uint32_t* gaux, int nq, int64_t n_groups) {
-    return gaux ? launch_scan_x<STORE, G, NRB, true>(h, s, qfrag, mask, gmax, gaux, nq, n_groups)
-                : launch_scan_x<STORE, G, NRB, false>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
 }
 
 template <typename STORE>
 hipError_t launch_scan_g(const hr_index* h, hipStream_t s, int G, const chunk_t* qfrag, const uint8_t* mask,
-                         float* gmax, uint32_t* gaux, int nq, int64_t n_groups) {
+                         float* gmax, int nq, int64_t n_groups) {
     // n_groups here counts SUPER-groups (64 rows) = the scan's loop bound
     if (group_rows_for(h, h->n_rows) == 16) {
         switch (G) {
-            case 1: return launch_scan<STORE, 1, 1>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
-            case 2: return launch_scan<STORE, 2, 1>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
-            case 3: return launch_scan<STORE, 3, 1>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
-            default: return launch_scan<STORE, 4, 1>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
+            case 1: return launch_scan<STORE, 1, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
+            case 2: return launch_scan<STORE, 2, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
+            case 3: return launch_scan<STORE, 3, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
+            default: return launch_scan<STORE, 4, 1>(h, s, qfrag, mask, gmax, nq, n_groups);
         }
     }
     switch (G) {
-        case 1: return launch_scan<STORE, 1, 4>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
-        case 2: return launch_scan<STORE, 2, 4>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
-        case 3: return launch_scan<STORE, 3, 4>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
-        default: return launch_scan<STORE, 4, 4>(h, s, qfrag, mask, gmax, gaux, nq, n_groups);
+        case 1: return launch_scan<STORE, 1, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
+        case 2: return launch_scan<STORE, 2, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
+        case 3: return launch_scan<STORE, 3, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
+        default: return launch_scan<STORE, 4, 4>(h, s, qfrag, mask, gmax, nq, n_groups);
     }
 }
 
 // Large-batch pass (dense_scan_bigq_kernel): GQ query groups streamed through LDS in k-chunks.
-template <typename STORE, int GQ, int NRB, bool AUX>
-hipError_t launch_scan_bigq_x(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
-                              uint32_t* gaux, int nq, int64_t n_super) {
-    auto kern = dense_scan_bigq_kernel<STORE, GQ, NRB, AUX>;
+template <typename STORE, int GQ, int NRB>
+hipError_t launch_scan_bigq(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                            int nq, int64_t n_super) {
+    auto kern = dense_scan_bigq_kernel<STORE, GQ, NRB>;
     const size_t lds = (size_t)2 * GQ * 2 * 1024;  // 2 buffers x GQ groups x BKT(2) fragments of 1 KiB
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int64_t blocks = std::min<int64_t>((n_super + 7) / 8, (int64_t)scan_cus(h));
     blocks = std::max<int64_t>(blocks, 1);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, h->tiles.as<chunk_t>(), qfrag,
-                       h->scale.as<float>(), mask, gmax, gaux, nq, h->KT, h->n_rows, n_super);
+                       h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
     return hipGetLastError();
-}
-template <typename STORE, int GQ, int NRB>
-hipError_t launch_scan_bigq(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
-                            uint32_t* gaux, int nq, int64_t n_super) {
-    return gaux ? launch_scan_bigq_x<STORE, GQ, NRB, true>(h, s, qfrag, mask, gmax, gaux, nq, n_super)
-                : launch_scan_bigq_x<STORE, GQ, NRB, false>(h, s, qfrag, mask, gmax, gaux, nq, n_super);
 }
 template <typename STORE>
 hipError_t launch_scan_bigq_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask,
-                              float* gmax, uint32_t* gaux, int nq, int64_t n_super) {
-    return group_rows_for(h, h->n_rows) == 16 ? launch_scan_bigq<STORE, 8, 1>(h, s, qfrag, mask, gmax, gaux, nq, n_super)
-                                              : launch_scan_bigq<STORE, 8, 4>(h, s, qfrag, mask, gmax, gaux, nq, n_super);
+                              float* gmax, int nq, int64_t n_super) {
+    return group_rows_for(h, h->n_rows) == 16 ? launch_scan_bigq<STORE, 8, 1>(h, s, qfrag, mask, gmax, nq, n_super)
+                                              : launch_scan_bigq<STORE, 8, 4>(h, s, qfrag, mask, gmax, nq, n_super);
 }
 
 // 256-query pass with the queries in registers and the corpus streamed through LDS (dense_scan_qreg_kernel):
@@ -614,7 +600,6 @@ enum { PHASE_SCAN = 1, PHASE_FINISH = 2, PHASE_PREP = 4, PHASE_ALL = 7 };
 // One block per (query, modality): worth it when the batch fills a good part of the chip that way and the candidate
 // set fits LDS; otherwise the multi-launch chain, whose refine kernels spread ONE query over many compute units
 // (single-query latency path, escalated searches with hundreds of candidate groups).
-bool g_use_aux = true;  // hr_debug_option(HR_DEBUG_NO_GROUP_AUX): refine every row of every candidate group (the round-2 rule)
 int g_finish_mode = 0;  // hr_debug_option(HR_DEBUG_FINISH_MODE): 0 = by batch size, 1 = always the chain, 2 = fused whenever it fits
 bool finish_fused_ok(int B, int n_mod, int C, int GR, int64_t n_groups) {
     const int64_t n_buckets = (n_groups + kBucketGroups - 1) / kBucketGroups;
@@ -658,7 +643,6 @@ FinishMod finish_mod_dense(hr_index* h, Workspace* ws, const float* d_q, int B, 
     m.qn2 = ws->qn2.as<double>();
     m.norm2 = h->norm2.as<double>();
     m.n_rows = h->n_rows;
-    m.gaux = ws->aux_valid ? ws->gaux.as<uint32_t>() : nullptr;
     return m;
 }
 FinishMod finish_mod_sparse(hr_index* h, Workspace* ws, const int64_t* d_qptr, const int32_t* d_qidx, const float* d_qval,
@@ -690,7 +674,7 @@ FinishMod finish_mod_sparse(hr_index* h, Workspace* ws, const int64_t* d_qptr, c
 // maxima in ws), PHASE_FINISH = candidate select + refine + top-k from those maxima.
 int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float* d_q, int B, int k,
                          const uint8_t* d_mask, int64_t* d_ids, float* d_scores, int32_t* d_flags, int C,
-                         hipEvent_t scan_done = nullptr, int phases = PHASE_ALL, int n_mod = 1) {
+                         hipEvent_t scan_done = nullptr, int phases = PHASE_ALL) {
     const int GR = group_rows_for(h, h->n_rows);
     const int64_t n_super = (h->n_rows + kSuperRows - 1) / kSuperRows;
     const int64_t n_groups = n_super * (kSuperRows / GR);  // group maxima per query (tail groups hold -inf)
@@ -703,10 +687,6 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     const int Gmax = big256 ? 16 : big ? 8 : Gsmall;
     const int chunk_q = 16 * Gmax;
     const int n_chunks = (B + chunk_q - 1) / chunk_q;
-    // The groups' auxiliary words (best row + runner-up, dense.h) are worth writing when the finishing kernel that can
-    // use them will run (a batch that fills the chip) and the scan kernel of this batch size emits them.
-    const bool want_aux = g_use_aux && !big256 && finish_fused_ok(B, n_mod, C, GR, n_groups);
-    if (want_aux) HIP_TRY(h, ws->gaux.ensure((size_t)B * n_groups * sizeof(uint32_t)));
     const size_t chunk_frag = (size_t)Gmax * h->KT * kTileChunks;   // 16-byte chunks of one pass's query fragments
     HIP_TRY(h, ws->qfrag.ensure((size_t)n_chunks * chunk_frag * sizeof(chunk_t)));
     HIP_TRY(h, ws->qn2.ensure((size_t)B * sizeof(double)));
@@ -737,21 +717,19 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
         {
             Span sp(h, s, PH_SCAN);
             float* gm = ws->gmax.as<float>() + (int64_t)c0 * n_groups;
-            uint32_t* ga = want_aux ? ws->gaux.as<uint32_t>() + (int64_t)c0 * n_groups : nullptr;
             hipError_t e;
             if (pass256)
                 e = use_qreg ? launch_scan_qreg_g(h, s, qf, d_mask, gm, nq, n_super)
                              : launch_scan_gemm_g<16>(h, s, qf, d_mask, gm, nq, n_super);
             else if (big)
-                e = (h->dtype == HR_F16) ? launch_scan_bigq_g<_Float16>(h, s, qf, d_mask, gm, ga, nq, n_super)
-                                         : launch_scan_bigq_g<float>(h, s, qf, d_mask, gm, ga, nq, n_super);
+                e = (h->dtype == HR_F16) ? launch_scan_bigq_g<_Float16>(h, s, qf, d_mask, gm, nq, n_super)
+                                         : launch_scan_bigq_g<float>(h, s, qf, d_mask, gm, nq, n_super);
             else
-                e = (h->dtype == HR_F16) ? launch_scan_g<_Float16>(h, s, G, qf, d_mask, gm, ga, nq, n_super)
-                                         : launch_scan_g<float>(h, s, G, qf, d_mask, gm, ga, nq, n_super);
+                e = (h->dtype == HR_F16) ? launch_scan_g<_Float16>(h, s, G, qf, d_mask, gm, nq, n_super)
+                                         : launch_scan_g<float>(h, s, G, qf, d_mask, gm, nq, n_super);
             HIP_TRY(h, e);
         }
     }
-    if (phases & PHASE_SCAN) ws->aux_valid = want_aux;
     if (scan_done) HIP_TRY(h, hipEventRecord(scan_done, s));
     if (!(phases & PHASE_FINISH)) return HR_OK;
     if (finish_fused_ok(B, 1, C, GR, n_groups)) {
@@ -1611,7 +1589,7 @@ static int hybrid_scan_phases(hr_index* h, const float* d_q, const int64_t* d_q_
         h->slot_prepped[slot] = false;
     }
     if (h->n_rows > 0)
-        HR_TRY(dense_search_enqueue(h, wd, s, d_q, B, k, d_rowmask, nullptr, nullptr, nullptr, C, nullptr, phases, 2));
+        HR_TRY(dense_search_enqueue(h, wd, s, d_q, B, k, d_rowmask, nullptr, nullptr, nullptr, C, nullptr, phases));
     if (h->n_sparse > 0)
         HR_TRY(sparse_search_enqueue(h, wsp, s, d_q_indptr, d_q_idx, d_q_val, B, max_q_nnz, k, d_rowmask, nullptr,
                                      nullptr, nullptr, C, phases));
@@ -1810,9 +1788,6 @@ int hr_debug_option(hr_index* h, int key, int value) {
         case HR_DEBUG_GROUP_ROWS:
             if (value != 0 && value != 16 && value != 64) return fail(h, HR_EINVAL, "group rows must be 0, 16 or 64");
             g_group_rows = value;
-            return HR_OK;
-        case HR_DEBUG_NO_GROUP_AUX:
-            g_use_aux = value == 0;
             return HR_OK;
         case HR_DEBUG_FAIL_NEXT_BUILD:
             if (!h) return fail(nullptr, HR_EINVAL, "null handle");

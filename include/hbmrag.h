@@ -348,12 +348,9 @@ HR_API int hr_set_scan_cus(hr_index* h, int n_cus);
  * HR_DEBUG_SPARSE_RPB (process-wide): doc ranges one sparse-scan block walks (0 = by shard size).
  * HR_DEBUG_GROUP_ROWS (process-wide): rows per candidate group (16 or 64; 0 = by shard size) of handles created
  *   afterwards.
- * The library reads no environment variables.
- * HR_DEBUG_NO_GROUP_AUX (process-wide): value != 0 switches off the groups' auxiliary words (best row + runner-up, written
- *   by the dense scan, used by the fused finishing kernel to refine one row per candidate group first): every row of
- *   every candidate group is refined, as in round 2 — for A/B measurements and for tests that compare the two rules. */
+ * The library reads no environment variables. */
 enum { HR_DEBUG_FINISH_MODE = 1, HR_DEBUG_FAIL_NEXT_BUILD = 2, HR_DEBUG_DENSE_KERNELS = 3, HR_DEBUG_SPARSE_RPB = 4,
-       HR_DEBUG_GROUP_ROWS = 5, HR_DEBUG_NO_GROUP_AUX = 6 };
+       HR_DEBUG_GROUP_ROWS = 5 };
 HR_API int hr_debug_option(hr_index* h, int key, int value);
 
 /* ---- measurement hooks -------------------------------------------------------

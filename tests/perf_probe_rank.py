@@ -41,26 +41,23 @@ cfg = EngineConfig(top_k=20)
 dQ = [torch.from_numpy(Q[i]).to(dev) for i in range(8)]
 
 ARRANGEMENTS = [
-    # name, finish mode (1 chain, 2 fused), prep stream, light CUs, depth, group aux (best row first)
-    ("r2_like_chain_noprep", 1, False, 0, 3, False),
-    ("chain_prep", 1, True, 0, 3, False),
-    ("fused_prep_noaux", 2, True, 0, 3, False),
-    ("fused_prep", 2, True, 0, 3, True),
-    ("fused_noprep", 2, False, 0, 3, True),
-    ("fused_prep_depth2", 2, True, 0, 2, True),
-    ("fused_prep_depth4", 2, True, 0, 4, True),
-    ("fused_prep_cu16", 2, True, 16, 3, True),
-    ("fused_prep_cu24", 2, True, 24, 3, True),
-    ("fused_prep_cu32", 2, True, 32, 3, True),
-    ("fused_prep_cu48", 2, True, 48, 3, True),
-    ("fused_prep_cu64", 2, True, 64, 3, True),
+    # name, finish mode, prep stream, light CUs, depth
+    ("r2_like_chain_noprep", 1, False, 0, 3),
+    ("chain_prep", 1, True, 0, 3),
+    ("fused_noprep", 2, False, 0, 3),
+    ("fused_prep", 2, True, 0, 3),
+    ("fused_prep_depth2", 2, True, 0, 2),
+    ("fused_prep_depth4", 2, True, 0, 4),
+    ("fused_prep_cu16", 2, True, 16, 3),
+    ("fused_prep_cu32", 2, True, 32, 3),
+    ("fused_prep_cu64", 2, True, 64, 3),
+    ("chain_prep_cu32", 1, True, 32, 3),
 ]
 
-for name, mode, prep, cus, depth, aux in ARRANGEMENTS:
+for name, mode, prep, cus, depth in ARRANGEMENTS:
     if ONLY and name not in ONLY:
         continue
     nat.debug_option(nat.HR_DEBUG_FINISH_MODE, mode)
-    nat.debug_option(nat.HR_DEBUG_NO_GROUP_AUX, 0 if aux else 1)
     try:
         eng = PipelinedSearchEngine(h, cfg, device=str(dev), depth=depth, simulate_ranks=SIM, light_cus=cus, prep_stream=prep)
     except Exception as e:  # e.g. CU masks refused on this box
@@ -123,10 +120,9 @@ for name, mode, prep, cus, depth, aux in ARRANGEMENTS:
                                                                   out["rr_orig"].data_ptr(), st.cuda_stream))
         pieces["empty_launch_pair_us"] = timed(lambda: (torch.cuda._sleep(1), torch.cuda._sleep(1)))
     print(json.dumps({"arrangement": name, "rows": N, "simulate_ranks": SIM, "depth": depth, "light_cus": cus, "prep_stream": prep,
-                      "finish": {1: "chain", 2: "fused"}[mode], "best_row_first": aux, **res, "phases_ms": phases, "all_exact": exact,
+                      "finish": {1: "chain", 2: "fused"}[mode], **res, "phases_ms": phases, "all_exact": exact,
                       "finish_alone_us": fin_us, "post_alone_us": post_us, "post_pieces": pieces,
                       "dense_scan_frac_hbm": h.dense_scan_bytes / (phases.get("dense_scan", 1e9) * 1e-3) / 8e12}), flush=True)
     eng.close()
 nat.debug_option(nat.HR_DEBUG_FINISH_MODE, 0)
-nat.debug_option(nat.HR_DEBUG_NO_GROUP_AUX, 0)
 h.close()
