@@ -49,7 +49,9 @@ ARRANGEMENTS = [
     ("fused_prep_depth2", 2, True, 0, 2),
     ("fused_prep_depth4", 2, True, 0, 4),
     ("fused_prep_cu16", 2, True, 16, 3),
+    ("fused_prep_cu24", 2, True, 24, 3),
     ("fused_prep_cu32", 2, True, 32, 3),
+    ("fused_prep_cu48", 2, True, 48, 3),
     ("fused_prep_cu64", 2, True, 64, 3),
     ("chain_prep_cu32", 1, True, 32, 3),
 ]
