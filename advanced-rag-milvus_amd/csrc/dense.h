@@ -267,14 +267,12 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
 // L2: L2 : HBM traffic = 1 : 1.  MFMA work per corpus KiB is GQ x 16 cycles per
 // SIMD (GQ = 16: 64 cycles per KiB per CU against ~100 cycles per KiB of HBM
 // supply), so the pass stays HBM-bound.
-// BKT = k-steps per query chunk; the corpus ring holds two chunks (PF = 2 BKT k-steps x 2 row blocks per wave): BKT = 2
-// keeps 64 KB of corpus loads in flight per compute unit, BKT = 4 (rows of a multiple of 8 tiles) 128 KB.
-template <typename STORE, int GQ, int NRB, int BKT = 2>
+template <typename STORE, int GQ, int NRB>
 __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
     const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
     const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int KT, int64_t n_rows,
     int64_t n_super) {
-    constexpr int RS = 2, PF = 2 * BKT;  // query chunk = BKT k-steps (8 BKT staging registers), corpus ring = 2 BKT k-steps
+    constexpr int RS = 2, BKT = 2, PF = 4;  // query chunk = 2 k-steps (16 staging registers), corpus ring = 4 k-steps
     constexpr int kPairs = kRowBlocksPerSuper / RS;
     constexpr int kFrags = GQ * BKT;           // 1 KiB query fragments per k-chunk
     constexpr int kStage = kFrags / 8;         // fragments each of the 8 waves stages per chunk

@@ -331,11 +331,6 @@ int group_rows_for(const hr_index* h, int64_t n) {
     return n > 3000000 ? 64 : 16;
 }
 
-// hr_debug_option(HR_DEBUG_DENSE_KERNELS) bit mask; see hbmrag.h (bit 16: keep the 4-step corpus ring of the 128-query scan)
-int g_dense_kernels = 0;
-int g_sparse_rpb = 0;     // HR_DEBUG_SPARSE_RPB: doc ranges per sparse-scan block (0 = by shard size)
-int g_group_rows = 0;     // HR_DEBUG_GROUP_ROWS: candidate-group size of handles created from now on (0 = by shard size)
-
 // ---- dense launch helpers ----------------------------------------------------
 template <typename STORE, int G, int NRB>
 hipError_t launch_scan(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
@@ -385,11 +380,11 @@ hipError_t launch_scan_g(const hr_index* h, hipStream_t s, int G, const chunk_t*
 }
 
 // Large-batch pass (dense_scan_bigq_kernel): GQ query groups streamed through LDS in k-chunks.
-template <typename STORE, int GQ, int NRB, int BKT>
-hipError_t launch_scan_bigq_x(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
-                              int nq, int64_t n_super) {
-    auto kern = dense_scan_bigq_kernel<STORE, GQ, NRB, BKT>;
-    const size_t lds = (size_t)2 * GQ * BKT * 1024;  // 2 buffers x GQ groups x BKT fragments of 1 KiB
+template <typename STORE, int GQ, int NRB>
+hipError_t launch_scan_bigq(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                            int nq, int64_t n_super) {
+    auto kern = dense_scan_bigq_kernel<STORE, GQ, NRB>;
+    const size_t lds = (size_t)2 * GQ * 2 * 1024;  // 2 buffers x GQ groups x BKT(2) fragments of 1 KiB
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     int64_t blocks = std::min<int64_t>((n_super + 7) / 8, (int64_t)scan_cus(h));
@@ -397,14 +392,6 @@ hipError_t launch_scan_bigq_x(const hr_index* h, hipStream_t s, const chunk_t* q
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, h->tiles.as<chunk_t>(), qfrag,
                        h->scale.as<float>(), mask, gmax, nq, h->KT, h->n_rows, n_super);
     return hipGetLastError();
-}
-template <typename STORE, int GQ, int NRB>
-hipError_t launch_scan_bigq(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
-                            int nq, int64_t n_super) {
-    // the deeper corpus ring needs rows of a multiple of 8 tiles (D = 768, 1024, ...); bit 16 of HR_DEBUG_DENSE_KERNELS
-    // keeps the 4-step ring for A/B measurements
-    if (h->KT % 8 == 0 && !(g_dense_kernels & 16)) return launch_scan_bigq_x<STORE, GQ, NRB, 4>(h, s, qfrag, mask, gmax, nq, n_super);
-    return launch_scan_bigq_x<STORE, GQ, NRB, 2>(h, s, qfrag, mask, gmax, nq, n_super);
 }
 template <typename STORE>
 hipError_t launch_scan_bigq_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask,
@@ -418,6 +405,9 @@ hipError_t launch_scan_bigq_g(const hr_index* h, hipStream_t s, const chunk_t* q
 // hr_debug_option(HR_DEBUG_DENSE_KERNELS) bit mask (tests drive every scan kernel at every shape): 1 = no register-
 // resident 256-query pass, 2 = no tiled-contraction pass, 4 = no k-chunked large-batch pass, 8 = prefer the tiled
 // contraction to the register-resident pass where both apply
+int g_dense_kernels = 0;
+int g_sparse_rpb = 0;     // HR_DEBUG_SPARSE_RPB: doc ranges per sparse-scan block (0 = by shard size)
+int g_group_rows = 0;     // HR_DEBUG_GROUP_ROWS: candidate-group size of handles created from now on (0 = by shard size)
 bool qreg_supported(const hr_index* h) {
     return !(g_dense_kernels & 1) && h->dtype == HR_F16 && h->KT == 24;
 }
@@ -1788,7 +1778,7 @@ int hr_debug_option(hr_index* h, int key, int value) {
             g_finish_mode = value;
             return HR_OK;
         case HR_DEBUG_DENSE_KERNELS:
-            if (value < 0 || value > 31) return fail(h, HR_EINVAL, "dense kernel mask must be 0..31");
+            if (value < 0 || value > 15) return fail(h, HR_EINVAL, "dense kernel mask must be 0..15");
             g_dense_kernels = value;
             return HR_OK;
         case HR_DEBUG_SPARSE_RPB:

@@ -36,7 +36,6 @@ for b in range(-(-N // BLK)):
 h.finalize()
 print(f"shard {N} rows built in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
 
-nat.debug_option(nat.HR_DEBUG_DENSE_KERNELS, int(os.environ.get("PROBE_DENSE_MASK", "0")))   # e.g. 16 = 4-step corpus ring
 Q, SQ = bench.make_queries(8, B, D)
 cfg = EngineConfig(top_k=20)
 dQ = [torch.from_numpy(Q[i]).to(dev) for i in range(8)]

@@ -28,8 +28,7 @@ def options():
 @pytest.mark.parametrize("mask", [8,        # tiled contraction preferred for 129..256 queries at D = 768
                                   1,        # no register-resident pass: tiled contraction
                                   1 | 2,    # neither 256-query pass: 128-query passes
-                                  4,        # no large-batch pass at all: 64-query passes
-                                  16])      # the large-batch pass with its 4-step corpus ring (the default ring is 8 deep where rows allow)
+                                  4])       # no large-batch pass at all: 64-query passes
 def test_dense_kernel_variants_match_the_oracle(gpu, options, mask):
     options(nat.HR_DEBUG_DENSE_KERNELS, mask)
     rng = np.random.default_rng(7)
