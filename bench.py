@@ -230,6 +230,8 @@ def main():
                          "(CU-masked HIP streams); 0 = no masks, stream priorities only")
     ap.add_argument("--no-prep-stream", action="store_true", help="query prep on the scan stream (the round-2 arrangement)")
     ap.add_argument("--group-rows", type=int, choices=(0, 16, 64), default=0, help="rows per candidate group (0 = by shard size)")
+    ap.add_argument("--dense-kernel-mask", type=int, default=0,
+                    help="hr_debug_option(HR_DEBUG_DENSE_KERNELS) bit mask for A/B runs")
     ap.add_argument("--finish-mode", choices=("auto", "chain", "fused"), default="auto",
                     help="finishing path: auto = fused kernel for batches that fill the chip, chain = five launches")
     args = ap.parse_args()
@@ -277,6 +279,7 @@ def main():
     N, D, B, blk = args.rows, args.dim, args.batch, min(args.block_rows, args.rows)
     lo, hi = shard_range(N, rank, world, align=blk)
     n_local = hi - lo
+    nat.debug_option(nat.HR_DEBUG_DENSE_KERNELS, args.dense_kernel_mask)
     nat.debug_option(nat.HR_DEBUG_GROUP_ROWS, args.group_rows)
     h = nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE, SPARSE_DIM if use_sparse else 0, local_rank)
     nat.debug_option(nat.HR_DEBUG_GROUP_ROWS, 0)
@@ -641,6 +644,7 @@ def main():
                        "streams": ("heavy (scans) + light (finish, exchange, post)" + ("" if args.no_prep_stream else " + prep (query preparation)")
                                    + (f"; CU masks: {args.light_cus} CUs for light + prep, the rest for the scans" if args.light_cus else "; priorities only")) if n_fly > 1 else "one stream",
                        "finish": args.finish_mode, "group_rows": args.group_rows or "by shard size",
+                       **({"dense_kernel_mask": args.dense_kernel_mask} if args.dense_kernel_mask else {}),
                        **({"simulate_ranks": sim, "projection": f"per-rank step of a {N * sim}-row corpus on {sim} GPUs: the merge of {sim} lists per modality "
                            "runs on the finishing stream, the all-gather itself is NOT included"} if sim else {}),
                        "parallelism": f"row-sharded x{world}, one RCCL all-gather of per-shard top-k' per step" if world > 1 else "single GPU"},
