@@ -1103,7 +1103,7 @@ int build_sparse(hr_index* h) {
 // =============================================================================
 extern "C" {
 
-int hr_version(void) { return 100; }
+int hr_version(void) { return 10300; }  // 1.3.0: round 3 (fused finishing + post kernels, device filters, attention, masked streams)
 
 const char* hr_last_error(const hr_index* h) {
     if (!h) return g_last_error.c_str();
