@@ -148,6 +148,9 @@ class SearchCoalescer:
         """Rounds of the torchrun form: the dense and the sparse searches of the callers that share (top_k, filter
         expression, drop ratio) travel in one packet; other combinations take a round of their own."""
         cs = self.mgr._main
+        if getattr(cs.dev, "type", "cpu") == "cuda":   # the current device is a per-thread setting: the collectives of this
+            import torch                                # thread must run on the rank's GPU
+            torch.cuda.set_device(cs.dev)
         while True:
             reqs = self._collect()
             if reqs is None:

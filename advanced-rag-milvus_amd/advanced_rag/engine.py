@@ -402,7 +402,7 @@ class PipelinedSearchEngine(HybridSearchEngine):
 
     def __init__(self, handle, config: Optional[EngineConfig] = None, process_group=None, device: Optional[str] = None,
                  depth: int = 2, domain_handle=None, simulate_ranks: int = 0, light_cus: int = 0,
-                 prep_stream: bool = True):
+                 prep_stream: bool = False):
         super().__init__(handle, config, process_group, device, domain_handle=domain_handle,
                          simulate_ranks=simulate_ranks)
         if not self.cfg.use_sparse:
@@ -420,9 +420,11 @@ class PipelinedSearchEngine(HybridSearchEngine):
         # (Swapping the priorities — scans high, finishing work normal — measures the same: 0.611 against 0.618 ms per
         # step on a rank-sized shard, 3.83 against 3.77 ms at 10M rows.)
         #
-        # A third stream (PREP) carries the query preparation of every batch (fragment-order queries, |q|^2, the sparse
-        # queries' fixed-point scale): a handful of short, nearly empty launches that would otherwise sit between the
-        # scans on the heavy stream and leave the chip idle there (~25 us of a 0.6 ms step on a rank-sized shard).
+        # prep_stream=True gives the query preparation of every batch (fragment-order queries, |q|^2, the sparse queries'
+        # fixed-point scale: a handful of short, nearly empty launches) a third stream, so that the heavy stream carries
+        # the scans only.  Measured on a rank-sized shard it buys nothing (0.605 against 0.613 ms per step with the
+        # five-launch chain, 0.60 - 0.69 against 0.59 with the fused finishing kernel: a third queue contending for the
+        # same compute units costs what the ~25 us of prep launches on the heavy stream cost), so it is off by default.
         #
         # light_cus > 0 confines the finishing + prep streams to the first `light_cus` compute units and the scans to
         # the rest (hr_stream_create CU masks; the scans' persistent grids are sized to their share).

@@ -228,7 +228,7 @@ def main():
     ap.add_argument("--light-cus", type=int, default=0,
                     help="confine the finishing + prep streams to this many compute units and the scans to the rest "
                          "(CU-masked HIP streams); 0 = no masks, stream priorities only")
-    ap.add_argument("--no-prep-stream", action="store_true", help="query prep on the scan stream (the round-2 arrangement)")
+    ap.add_argument("--prep-stream", action="store_true", help="query prep on a third stream instead of the scan stream")
     ap.add_argument("--group-rows", type=int, choices=(0, 16, 64), default=0, help="rows per candidate group (0 = by shard size)")
     ap.add_argument("--dense-kernel-mask", type=int, default=0,
                     help="hr_debug_option(HR_DEBUG_DENSE_KERNELS) bit mask for A/B runs")
@@ -335,7 +335,7 @@ def main():
     nat.debug_option(nat.HR_DEBUG_FINISH_MODE, {"auto": 0, "chain": 1, "fused": 2}[args.finish_mode])
     sim = args.simulate_ranks if world == 1 else 0
     eng = PipelinedSearchEngine(h, cfg, device=str(dev), depth=n_fly, simulate_ranks=sim, light_cus=args.light_cus,
-                                prep_stream=not args.no_prep_stream) if n_fly > 1 else \
+                                prep_stream=args.prep_stream) if n_fly > 1 else \
         HybridSearchEngine(h, cfg, device=str(dev), simulate_ranks=sim)
     dQ = [torch.from_numpy(Q[i]).to(dev) for i in range(n_batches)]
     dS = [eng.upload_sparse(pack_sparse_queries(SQ[i], 0.2)) if use_sparse else None for i in range(n_batches)]
@@ -641,7 +641,7 @@ def main():
                                                    else "(BASELINE config 5 on one GPU)" if (N, D, B, use_sparse) == (50_000_000, 1024, 256, False) else "")),
                        "rows": N, "dim": D, "batch": B, "top_k": args.top_k, "k_prime": kp,
                        "batches_in_flight": n_fly,
-                       "streams": ("heavy (scans) + light (finish, exchange, post)" + ("" if args.no_prep_stream else " + prep (query preparation)")
+                       "streams": ("heavy (scans) + light (finish, exchange, post)" + (" + prep (query preparation)" if args.prep_stream else "")
                                    + (f"; CU masks: {args.light_cus} CUs for light + prep, the rest for the scans" if args.light_cus else "; priorities only")) if n_fly > 1 else "one stream",
                        "finish": args.finish_mode, "group_rows": args.group_rows or "by shard size",
                        **({"dense_kernel_mask": args.dense_kernel_mask} if args.dense_kernel_mask else {}),
