@@ -127,16 +127,20 @@ def pmc_traffic(rows: int, dim: int, batch: int, n_gpus: int, kernel: str = "den
             with open(path) as f:
                 d = json.load(f)
             w = d.get("workload", {})
-            if n_gpus == 1 and (w.get("rows"), w.get("dim"), w.get("batch"), w.get("sparse_dist", "uniform")) == (rows, dim, batch, dist) \
-                    and kernel in d["kernels"]:
-                return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            if n_gpus == 1 and (w.get("rows"), w.get("dim"), w.get("batch"), w.get("sparse_dist", "uniform")) == (rows, dim, batch, dist):
+                # the NEWEST collection of this workload is the only one consulted: an older round's file lists kernels
+                # (the five-launch finishing chain) that a later round's step no longer launches
+                if kernel in d["kernels"]:
+                    return d["kernels"][kernel]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+                return None, None
         except Exception:
             continue
     return None, None
 
 
 # search kernels of a step; each is launched once (the selection kernels cover both modalities of a hybrid step in one launch)
-STEP_KERNELS = ("dense_scan", "sparse_scan", "refine_dense", "refine_sparse", "select_groups", "bucket_max", "select_topk")
+STEP_KERNELS = ("dense_scan", "sparse_scan", "refine_dense", "refine_sparse", "select_groups", "bucket_max", "select_topk",
+                "finish_fused", "post_lists")
 
 
 def step_hbm(rows: int, dim: int, batch: int, n_gpus: int, dist: str, use_sparse: bool, ms_per_step: float):

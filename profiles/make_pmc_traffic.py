@@ -15,7 +15,8 @@ from collections import defaultdict
 KERNELS = {"dense_scan": ("dense_scan_kernel", "dense_scan_bigq_kernel", "dense_scan_qreg_kernel", "dense_scan_gemm_kernel"),
            "sparse_scan": ("sparse_scan_kernel",), "refine_dense": ("refine_dense_kernel",),
            "refine_sparse": ("refine_sparse_kernel",), "select_groups": ("select_groups_kernel",),
-           "bucket_max": ("bucket_max_kernel",), "select_topk": ("select_topk_kernel",)}
+           "bucket_max": ("bucket_max_kernel",), "select_topk": ("select_topk_kernel",),
+           "finish_fused": ("finish_kernel",), "post_lists": ("post_lists_kernel",), "hybrid_prep": ("hybrid_prep_kernel",)}
 
 
 def per_kernel(path, counter):
