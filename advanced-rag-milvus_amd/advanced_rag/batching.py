@@ -10,6 +10,11 @@ round of scans is in flight — or within a short window of the first call of a 
 synchronisation per round, and the per-query lists are handed back to the awaiting coroutines.  Lists the device form
 could not prove exact are redone through the host form, which widens the candidate set by itself.
 
+A caller that has BOTH embeddings of a request in hand (HybridRetriever._retrieve_inner via
+MilvusIndexManager.hybrid_search) submits one "hybrid" request instead of two searches and a fusion: the batch runs as
+one `hr_search_hybrid_dev` (both scans, the fused finishing kernel) + one `hr_post_lists_dev` (RRF) — the engine's own
+step — and the caller gets the fused top-k with the per-modality scores in ONE round instead of two.
+
 One worker thread per manager; the event loop never blocks on the GPU.
 """
 from __future__ import annotations
@@ -52,7 +57,8 @@ class SearchCoalescer:
         # broadcast + ONE gather for all the dense and sparse searches that share (top_k, filter, drop ratio)
         self.collective = hasattr(getattr(manager, "_main", None), "round")
         self.stats = {"rounds": 0, "requests": 0, "dense_launches": 0, "sparse_launches": 0, "fuse_launches": 0,
-                      "max_batch_seen": 0, "redone_unproven": 0, "busy_s": 0.0}
+                      "hybrid_launches": 0, "max_batch_seen": 0, "redone_unproven": 0, "busy_s": 0.0}
+        self._engines: Dict[Tuple, Any] = {}   # hybrid engines per (top_k, weights, rrf_k)
 
     # ------------------------------------------------------------------ front
     def submit(self, kind: str, key: Tuple, payload: Any) -> Future:
@@ -107,7 +113,7 @@ class SearchCoalescer:
         dev = torch.device("cuda", self.mgr.device)
         # one stream per kind of work: the dense and the sparse searches of a round run side by side (a lone retrieve()
         # overlaps its two scans, as its two worker threads did before the front existed)
-        streams = {k: torch.cuda.Stream(dev) for k in ("dense", "sparse", "fuse")}
+        streams = {k: torch.cuda.Stream(dev) for k in ("dense", "sparse", "fuse", "hybrid")}
         while True:
             reqs = self._collect()
             if reqs is None:
@@ -123,8 +129,9 @@ class SearchCoalescer:
                 stream = streams[kind]
                 used.add(kind)
                 with torch.cuda.stream(stream):
-                    for c0 in range(0, len(rs), self.max_batch):
-                        chunk = rs[c0:c0 + self.max_batch]
+                    step = min(self.max_batch, 128) if kind == "hybrid" else self.max_batch
+                    for c0 in range(0, len(rs), step):
+                        chunk = rs[c0:c0 + step]
                         self.stats["max_batch_seen"] = max(self.stats["max_batch_seen"], len(chunk))
                         try:
                             launched.append((kind, key, chunk, getattr(self, "_enqueue_" + kind)(torch, dev, stream, key, chunk)))
@@ -202,6 +209,8 @@ class SearchCoalescer:
             try:
                 if kind == "fuse":
                     r.future.set_result(self.mgr._fuse_rows_blocking(r.payload, key))
+                elif kind == "hybrid":
+                    r.future.set_result(None)   # the caller falls back to two searches + a fusion
                 else:
                     coll_name, top_k, expr, params_key = key
                     r.future.set_result(self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
@@ -267,6 +276,60 @@ class SearchCoalescer:
                     r.future.set_result((ids[i], sc[i]))
             except Exception as e:
                 r.future.set_exception(e)
+
+    # ------------------------------------------------------------------ hybrid (both searches + RRF of a request)
+    def _enqueue_hybrid(self, torch, dev, stream, key, chunk):
+        from .engine import EngineConfig, HybridSearchEngine
+        top_k, expr, drop, dw, sw, rrf_k = key
+        handle = self.mgr.collections["semantic_index"].handle.first
+        ekey = (top_k, dw, sw, rrf_k)
+        eng = self._engines.get(ekey)
+        if eng is None:
+            if len(self._engines) >= 16:     # weight adapters can produce many weight pairs: keep the buffers bounded
+                self._engines.clear()
+            eng = self._engines[ekey] = HybridSearchEngine(
+                handle, EngineConfig(top_k=top_k, dense_weight=dw, sparse_weight=sw, rrf_k=rrf_k, enable_reranking=False),
+                device=str(dev))
+        B = len(chunk)
+        dense = [r.payload[0] for r in chunk]
+        if all(hasattr(q, "is_cuda") and q.is_cuda for q in dense):
+            q = torch.stack([x.reshape(-1).to(torch.float32) for x in dense]).contiguous()
+        else:
+            host = np.stack([np.asarray(x.detach().cpu().numpy() if hasattr(x, "detach") else x, dtype=np.float32).reshape(-1)
+                             for x in dense])
+            q = torch.from_numpy(host).to(dev)
+        if q.shape[1] != handle.dim:
+            raise ValueError(f"query dim {q.shape[1]} != shard dim {handle.dim}")
+        ptr, idx, val, max_nnz = pack_sparse_queries([r.payload[1] for r in chunk], drop, handle.sparse_dim)
+        if not idx.size:
+            raise ValueError("no sparse terms in the batch")   # -> one by one through the general path
+        d_sparse = (torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(val).to(dev), int(max_nnz))
+        mask = self.mgr._device_row_mask(expr, "dense")
+        b = eng.search(q, d_sparse, rowmask=mask)
+        self.stats["hybrid_launches"] += 1
+        self.stats["dense_launches"] += 1
+        self.stats["sparse_launches"] += 1
+        return {"b": b, "keep": (q, d_sparse, mask)}
+
+    def _scatter_hybrid(self, key, chunk, st):
+        b = st["b"]
+        fi, fs = b["fused_ids"].cpu().numpy(), b["fused_scores"].cpu().numpy()
+        fm, fn = b["fused_methods"].cpu().numpy(), b["fused_n"].cpu().numpy()
+        ids, sc, fl = b["ids"].cpu().numpy(), b["scores"].cpu().numpy(), b["flags"].cpu().numpy()
+        # score of a fused row in the list its payload comes from: the dense list if the row is in it, else the sparse one
+        # (HybridRetriever._assemble_fused); rows are unique within a list
+        in_d = fi[:, :, None] == ids[0][:, None, :]
+        in_s = fi[:, :, None] == ids[1][:, None, :]
+        orig = np.where(in_d.any(axis=2), np.take_along_axis(sc[0], in_d.argmax(axis=2), axis=1),
+                        np.take_along_axis(sc[1], in_s.argmax(axis=2), axis=1))
+        proven = fl.min(axis=0) == 1
+        for i, r in enumerate(chunk):
+            if not proven[i]:   # ties at a candidate cut: the general path redoes the searches through the host forms
+                self.stats["redone_unproven"] += 1
+                r.future.set_result(None)
+                continue
+            n = int(fn[i])
+            r.future.set_result((fi[i, :n].copy(), fs[i, :n].copy(), fm[i, :n].copy(), orig[i, :n].copy()))
 
     # ------------------------------------------------------------------ fuse
     def _enqueue_fuse(self, torch, dev, stream, key, chunk):

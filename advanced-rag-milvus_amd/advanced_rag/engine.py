@@ -244,14 +244,15 @@ class HybridSearchEngine:
             b["scores"][m, :, :cfg.top_k].copy_(b["dom_scores"])
 
     # ------------------------------------------------------------------ one batch
-    def search(self, q, sparse=None, domain_q=None) -> dict:
+    def search(self, q, sparse=None, domain_q=None, rowmask=None) -> dict:
         """q: float32 [B, dim] device tensor.  sparse: (indptr int64[B+1], idx int32, val float32, max_nnz)
         device tensors from `upload_sparse`.  domain_q: float32 [B, domain_dim] device tensor for the optional
-        domain shard (engine built with domain_handle).  Asynchronous on the current stream; returns the
-        buffer dict (fused_* and rr_* tensors are the results; they are reused by the next call)."""
+        domain shard (engine built with domain_handle).  rowmask: packed uint8 device tensor (a filter expression's
+        rows, device_filters.py) applied to the dense and the sparse search.  Asynchronous on the current stream;
+        returns the buffer dict (fused_* and rr_* tensors are the results; they are reused by the next call)."""
         if self.stream is not None and self.torch.cuda.current_stream(self.device) != self.stream:
             with self.torch.cuda.stream(self.stream):
-                return self.search(q, sparse, domain_q)
+                return self.search(q, sparse, domain_q, rowmask)
         if domain_q is not None and self.hd is None:
             raise ValueError("domain queries need an engine built with domain_handle")
         t, cfg = self.torch, self.cfg
@@ -259,15 +260,16 @@ class HybridSearchEngine:
         b = self._buffers(B)
         kp = b["kp"]
         stream = t.cuda.current_stream(self.device).cuda_stream
+        d_mask = rowmask.data_ptr() if rowmask is not None else 0
         if cfg.use_sparse:
             indptr, idx, val, max_nnz = sparse
             # one call: dense scan alone on this stream, sparse chain overlapping the dense tail
             self.h.search_hybrid_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B,
                                      int(idx.shape[0]), int(max_nnz), kp, b["ids"].data_ptr(), b["scores"].data_ptr(),
-                                     b["flags"].data_ptr(), 0, stream)
+                                     b["flags"].data_ptr(), d_mask, stream)
         else:
             self.h.search_dense_dev(q.data_ptr(), B, kp, b["ids"][0].data_ptr(), b["scores"][0].data_ptr(),
-                                    b["flags"][0].data_ptr(), 0, stream)
+                                    b["flags"][0].data_ptr(), d_mask, stream)
         self._search_domain(b, domain_q, B, stream)
         return self._post_lists(b, B, stream)
 

@@ -704,6 +704,46 @@ class MilvusIndexManager:
             logging.error("shard search timeout for collection %s", collection_name)
             raise Exception(f"Search timeout for collection {collection_name}")
 
+    async def hybrid_search(self, dense_embedding, sparse_embedding, top_k: int, filters: Optional[str],
+                            weights: Sequence[float], rrf_k: int = 60, semantic_params: Optional[Dict] = None,
+                            sparse_params: Optional[Dict] = None):
+        """The semantic search (2 x top_k), the sparse search (2 x top_k) and their rank fusion for ONE request in ONE
+        round of the batching front: what `search` + `search` + `fuse_rank_lists_async` return, cut to the fused top_k.
+
+        -> [(hit dict as `search` formats it, with "score" = the score in the list the payload comes from (the semantic
+        list if the row is in it, else the sparse one), float64 fused score, method bit mask)] in fused order, or None
+        when this manager cannot answer that way (no front, sharded collection, a list the device form could not prove
+        exact, bad parameters ...) — the caller then takes the general path, which also owns the error behaviour."""
+        sem, spa = self.collections.get("semantic_index"), self.collections.get("sparse_index")
+        if sem is None or spa is None or sem.handle is not spa.handle or 2 * int(top_k) > self._native.HR_MAX_TOPK:
+            return None
+        front = self._coalescer(sem)
+        if front is None or front.collective:
+            return None
+        try:
+            self._search_params(sem, semantic_params)
+            sp = self._search_params(spa, sparse_params)
+            drop = float((sp.get("params") or sp).get("drop_ratio_search", 0.0))
+            payload = self._as_sparse_payload(sparse_embedding)
+        except Exception:
+            return None
+        if not len(payload[0]):
+            return None
+        w = list(weights) + [0.0] * (2 - len(weights))
+        fut = front.submit("hybrid", (int(top_k), filters, drop, float(w[0]), float(w[1]), int(rrf_k)), (dense_embedding, payload))
+        try:
+            res = await asyncio.wait_for(asyncio.wrap_future(fut), timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)
+        except asyncio.TimeoutError:
+            logging.error("shard search timeout for the hybrid request")
+            return []          # both searches of the request timed out: the general path would fuse two empty lists
+        except Exception:
+            return None
+        if res is None:
+            return None
+        rows, fused_scores, methods, orig = res
+        hits = self._format_hits(rows, orig)
+        return list(zip(hits, fused_scores.tolist(), methods.tolist()))
+
     @staticmethod
     def _fuse_inputs(row_lists, id_lists, weights, rrf_k):
         row_to_id = {}

@@ -176,12 +176,21 @@ class HybridRetriever:
         sparse_q = await self._get_sparse_embedding(query)
         expr = self._build_filter_expression(filters) if filters else None
 
+        fused = await self._retrieve_one_round(query, dense_q, sparse_q, expr) if not (use_domain_index and domain) else None
+        if fused is not None:
+            return self._tag_profile(fused, profile)[:self.config.top_k]
+
         searches = [self._search_semantic(dense_q, expr), self._search_sparse(sparse_q, expr)]
         if use_domain_index and domain:
             domain_q = await self._get_domain_embedding(query, domain)
             searches.append(self._search_domain(domain_q, expr))
         hit_lists = await asyncio.gather(*searches)
 
+        self._adapt_weights(query)
+        fused = await self._fuse_results_async(hit_lists[0], hit_lists[1], hit_lists[2] if len(hit_lists) > 2 else [])
+        return self._tag_profile(fused, profile)[:self.config.top_k]
+
+    def _adapt_weights(self, query: str) -> None:
         if self.weight_adapter:
             try:
                 dw, sw = self.weight_adapter(query)
@@ -192,14 +201,47 @@ class HybridRetriever:
             except Exception:
                 pass
 
-        fused = await self._fuse_results_async(hit_lists[0], hit_lists[1], hit_lists[2] if len(hit_lists) > 2 else [])
+    @staticmethod
+    def _tag_profile(fused: List[Dict[str, Any]], profile: str) -> List[Dict[str, Any]]:
         for hit in fused:
             meta = hit.get("metadata")
             if isinstance(meta, dict):
                 meta.setdefault("retrieval_profile", profile)
             else:
                 hit["retrieval_profile"] = profile
-        return fused[:self.config.top_k]
+        return fused
+
+    async def _retrieve_one_round(self, query: str, dense_q, sparse_q, expr: Optional[str]) -> Optional[List[Dict[str, Any]]]:
+        """Both searches and their rank fusion as ONE request to an index manager that offers `hybrid_search` (the HBM
+        manager's batching front: one device round per retrieve() instead of two, and only the fused top_k hits are
+        ever formatted).  Same lists, same arithmetic, same hit dicts as the general path below; None = take that path
+        (MMR needs the whole fused list; a manager without the entry point; a request it declined)."""
+        one_round = getattr(self.index_manager, "hybrid_search", None)
+        if one_round is None or self.config.enable_mmr:
+            return None
+        known = getattr(self.index_manager, "collections", None)
+        if known is None or "sparse_index" not in known or "semantic_index" not in known:
+            return None
+        cfg = self.config
+        saved = (cfg.dense_weight, cfg.sparse_weight)
+        self._adapt_weights(query)   # the adapter sees only the query: applying it before the searches changes nothing
+        try:
+            ranked = await one_round(dense_q, sparse_q, top_k=cfg.top_k, filters=expr,
+                                     weights=(cfg.dense_weight, cfg.sparse_weight), rrf_k=self.RRF_K,
+                                     semantic_params=cfg.semantic_search_params, sparse_params=cfg.sparse_search_params)
+        except Exception:  # pragma: no cover - the general path owns the error behaviour
+            logger.exception("one-round hybrid search failed; taking the general path")
+            ranked = None
+        if ranked is None:
+            cfg.dense_weight, cfg.sparse_weight = saved   # the general path applies the adapter itself
+            return None
+        now = datetime.utcnow()
+        fused = []
+        for hit, score, mask in ranked:
+            hit["method"] = _METHOD_ORDER[0] if mask & 1 else _METHOD_ORDER[1]
+            hit["original_score"] = hit["score"]
+            fused.append(self._finish_fused_hit(hit, score, [b for b in range(3) if (mask >> b) & 1], now))
+        return fused
 
     async def _tagged_search(self, method: str, embedding, collection: str, top_k: int, filters, params):
         try:
@@ -276,23 +318,24 @@ class HybridRetriever:
                 payload.setdefault(hit["id"], hit)
 
         now = datetime.utcnow()
-        fused: List[Dict[str, Any]] = []
-        for doc_id, score, seen_in in ranked:
-            hit = payload[doc_id]
-            hit.pop("_row", None)  # manager-internal row number (device rank fusion); not part of the reference's hit dict
-            hit["score"] = score
-            hit["retrieval_methods"] = [m for i, m in enumerate(_METHOD_ORDER) if i in seen_in]
-            meta = hit.get("metadata")
-            if isinstance(meta, dict) and meta.get("timestamp") and "recency" not in meta:   # "" never parses: no recency
-                try:
-                    age_days = max(0.0, (now - datetime.fromisoformat(str(meta["timestamp"]))).total_seconds() / 86400.0)
-                    meta["recency"] = float(1.0 / (1.0 + age_days))
-                except Exception:
-                    pass
-            fused.append(hit)
+        fused = [self._finish_fused_hit(payload[doc_id], score, seen_in, now) for doc_id, score, seen_in in ranked]
         if self.config.enable_mmr and fused:
             return self._mmr_diversify(fused, self.config.top_k, self.config.mmr_lambda)
         return fused
+
+    @staticmethod
+    def _finish_fused_hit(hit: Dict[str, Any], score: float, seen_in, now) -> Dict[str, Any]:
+        hit.pop("_row", None)  # manager-internal row number (device rank fusion); not part of the reference's hit dict
+        hit["score"] = score
+        hit["retrieval_methods"] = [m for i, m in enumerate(_METHOD_ORDER) if i in seen_in]
+        meta = hit.get("metadata")
+        if isinstance(meta, dict) and meta.get("timestamp") and "recency" not in meta:   # "" never parses: no recency
+            try:
+                age_days = max(0.0, (now - datetime.fromisoformat(str(meta["timestamp"]))).total_seconds() / 86400.0)
+                meta["recency"] = float(1.0 / (1.0 + age_days))
+            except Exception:
+                pass
+        return hit
 
     @staticmethod
     def _mmr_diversify(ranked: List[Dict[str, Any]], k: int, mmr_lambda: float) -> List[Dict[str, Any]]:

@@ -58,3 +58,36 @@ run("tanh gelu epilogue + HIP attention + recorded GEMM solutions", ce, profile=
 if os.environ.get("PROBE_TUNE") == "1":   # re-tune online (writes gpurun_out/tunableop_ce.csv): how the shipped file was made
     torch.cuda.tunable.tuning_enable(True)
     run("... re-tuned online", ce, tunable=True)
+
+
+def run_chunked(chunk):
+    """The same forward, `chunk` sequences at a time through ALL layers: the activations of a chunk (chunk x T x (384 + 1152
+    + 1536) halves) stay in the 256 MiB Infinity Cache between the kernels that write and read them."""
+    with torch.inference_mode():
+        parts = [(ids[a:a + chunk], types[a:a + chunk], mask[a:a + chunk]) for a in range(0, P, chunk)]
+        t0 = time.time()
+        for _ in range(2):
+            for p in parts:
+                ce.module(*p)
+        torch.cuda.synchronize()
+        warm = time.time() - t0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            for p in parts:
+                ce.module(*p)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        tf = P * ce.flops_per_pair(T) / (ms * 1e-3) / 1e12
+        mb = chunk * T * (384 + 1152 + 1536 + 384) * 2 / 1e6
+        print(f"chunks of {chunk:5d} sequences ({mb:6.1f} MB live) {ms:8.3f} ms/forward  {tf:7.1f} TFLOP/s = {tf / 2500:.3f} (warm-up {warm:.1f}s)", flush=True)
+
+
+if os.environ.get("PROBE_CHUNKS"):   # e.g. PROBE_CHUNKS=160,320,640,1280 ; tunes the chunk-sized GEMM shapes online first
+    torch.cuda.tunable.enable(True)
+    torch.cuda.tunable.tuning_enable(True)
+    torch.cuda.tunable.set_max_tuning_duration(150)
+    torch.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", "tunableop_ce_chunks.csv"))
+    for c in os.environ["PROBE_CHUNKS"].split(","):
+        run_chunked(int(c))

@@ -1,0 +1,119 @@
+"""Ad-hoc probe (not a test, no GPU): where the HOST time of `AdvancedRAGPipeline.retrieve()` goes under the reference's
+concurrency model (64 in-flight coroutines on one event loop).  The batching front is replaced by a stand-in that answers
+every round after `ROUND_MS` of sleep (GIL released, like a stream synchronisation) with well-formed lists, so everything
+else — the manager's search / fusion entry points, hit formatting, the retriever, rerank, evaluation, the audit trail — runs
+as in production.  Prints requests/s, process CPU per request and the top of a cProfile.
+
+    python tests/probes/api_cpu_profile.py [requests=2048] [in_flight=64] [round_ms=3.0] [profile=1] [one_round=1]
+"""
+import asyncio
+import contextlib
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "advanced-rag-milvus_amd"))
+from advanced_rag import AdvancedRAGPipeline, PipelineConfig  # noqa: E402
+from advanced_rag.batching import SearchCoalescer  # noqa: E402
+from advanced_rag.constants import RetrievalConstants  # noqa: E402
+from advanced_rag.indexing import MilvusIndexManager  # noqa: E402
+
+N_REQ = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+IN_FLIGHT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ROUND_MS = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0
+PROFILE = (sys.argv[4] != "0") if len(sys.argv) > 4 else True
+ONE_ROUND = (sys.argv[5] != "0") if len(sys.argv) > 5 else True   # 0: the general path (two searches + a fusion round)
+N_ROWS, DIM, SPARSE_DIM = 10_000_000, 768, 30_000
+
+
+class FakeHandle:
+    num_rows = N_ROWS
+    num_sparse_rows = N_ROWS
+    sparse_dim = SPARSE_DIM
+    dim = DIM
+    device = 0
+
+
+class FakeFront(SearchCoalescer):
+    def _run(self):
+        rng = np.random.default_rng(0)
+        while True:
+            reqs = self._collect()
+            if reqs is None:
+                return
+            time.sleep(ROUND_MS * 1e-3)
+            self.stats["rounds"] += 1
+            self.stats["requests"] += len(reqs)
+            for r in reqs:
+                if r.kind == "hybrid":
+                    k = r.key[0]
+                    r.future.set_result((rng.integers(0, N_ROWS, k), np.sort(rng.random(k))[::-1].copy(),
+                                         rng.integers(1, 4, k).astype(np.int32), rng.random(k).astype(np.float32)))
+                elif r.kind == "fuse":
+                    a, b, c = r.payload
+                    rows = np.unique(np.concatenate([a, b, c]))[:40]
+                    sc = np.sort(rng.random(rows.shape[0]))[::-1].copy()
+                    r.future.set_result((rows, sc, np.full(rows.shape[0], 3, np.int32)))
+                else:
+                    k = r.key[1]
+                    r.future.set_result((rng.integers(0, N_ROWS, k), np.sort(rng.random(k).astype(np.float32))[::-1].copy()))
+
+
+flatQ = np.random.default_rng(1).standard_normal((1024, DIM)).astype(np.float32)
+
+
+class Gen:
+    def encode_semantic(self, text):
+        return flatQ[int(text[1:]) % 1024]
+
+    def encode_sparse(self, text):
+        return {"indices": list(range(5, 400, 9)), "values": [0.5] * len(range(5, 400, 9))}
+
+    def encode_domain(self, text, domain=None):
+        return np.zeros(768, np.float32)
+
+
+mgr = MilvusIndexManager(semantic_dim=DIM, sparse_dim=SPARSE_DIM, connect=False)
+mgr.attach_shards([FakeHandle()], synthetic_rows=N_ROWS)
+mgr._front = FakeFront(mgr)
+mgr.embedding_generator = Gen()
+if not ONE_ROUND:
+    mgr.hybrid_search = None
+RetrievalConstants.TIMEOUT_SECONDS = 60.0
+pipe = AdvancedRAGPipeline(connect_to_milvus=False, config=PipelineConfig(top_k=20))
+pipe.index_manager = mgr
+pipe.retriever.index_manager = mgr
+
+
+async def burst(n_total, in_flight):
+    sem = asyncio.Semaphore(in_flight)
+
+    async def one(i):
+        async with sem:
+            res, _m = await pipe.retrieve(f"q{i}", context={"retrieval_profile": "default"})
+            assert 0 < len(res) <= pipe.config.rerank_top_k
+    await asyncio.gather(*[one(i) for i in range(n_total)])
+
+
+with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+    asyncio.run(burst(IN_FLIGHT, IN_FLIGHT))
+    prof = cProfile.Profile() if PROFILE else None
+    t0, c0 = time.perf_counter(), time.process_time()
+    if prof:
+        prof.enable()
+    asyncio.run(burst(N_REQ, IN_FLIGHT))
+    if prof:
+        prof.disable()
+    wall, cpu = time.perf_counter() - t0, time.process_time() - c0
+print(f"{N_REQ} requests, {IN_FLIGHT} in flight, {ROUND_MS} ms per round: {N_REQ / wall:.0f} requests/s, "
+      f"{cpu / N_REQ * 1e6:.0f} us of process CPU per request, rounds {mgr._front.stats['rounds']}")
+if prof:
+    st = pstats.Stats(prof)
+    st.sort_stats("cumulative").print_stats(45)
+    st.sort_stats("tottime").print_stats(30)
+mgr._front.close()

@@ -41,17 +41,25 @@ class TableGen:
 
 
 def _strip(hits):
-    return [(h["id"], float(h["score"]).hex(), tuple(h["retrieval_methods"]), h["metadata"]["chunk_index"]) for h in hits]
+    """Everything a hit dict of retrieve() carries, in comparable form."""
+    return [(h["id"], float(h["score"]).hex(), tuple(h["retrieval_methods"]), h["metadata"]["chunk_index"], h["method"],
+             float(h["original_score"]).hex(), h["content"], h["metadata"]["doc_id"], h["metadata"].get("retrieval_profile"),
+             tuple(sorted(h)))
+            for h in hits]
 
 
-def test_g5_reference_runs_issued_concurrently(gpu, long_timeout):
+@pytest.mark.parametrize("one_round", [True, False])
+def test_g5_reference_runs_issued_concurrently(gpu, long_timeout, one_round):
     """The 8 hybrid g5 runs of the reference, issued as concurrent coroutines through ONE manager: every coroutine gets
-    the reference's ids / fused scores / methods although its searches shared launches with the others."""
+    the reference's ids / fused scores / methods although its searches shared launches with the others — as one "hybrid"
+    request per retrieve() (both searches + the fusion in one round) and as two searches + a fusion round."""
     from advanced_rag.embedding_cache import initialize_caches
     g, X, csr, Q, SQ = g5_data.inputs()
     mgr = _g5_manager("float32", X, csr, True)
     initialize_caches()
     mgr.embedding_generator = TableGen(Q, SQ)
+    if not one_round:
+        mgr.hybrid_search = None
     retr = HybridRetriever(mgr, RetrievalConfig(top_k=20))
     runs = [r for r in g["runs"] if r["with_sparse"]]
 
@@ -65,7 +73,12 @@ def test_g5_reference_runs_issued_concurrently(gpu, long_timeout):
             assert [float(o["score"]).hex() for o in out] == run["scores"]
             assert [sorted(o["retrieval_methods"]) for o in out] == run["methods"]
         st = mgr._front.stats
-        assert st["requests"] == 3 * len(runs)                    # dense + sparse + fusion per retrieve()
+        if one_round:
+            assert st["requests"] == len(runs) + 3 * st["redone_unproven"]   # one request per retrieve()
+            assert 1 <= st["hybrid_launches"] < len(runs) and st["fuse_launches"] == 0
+        else:
+            assert st["requests"] == 3 * len(runs)                    # dense + sparse + fusion per retrieve()
+            assert st["hybrid_launches"] == 0
         assert st["dense_launches"] + st["sparse_launches"] < 2 * len(runs)   # they did share launches
     finally:
         asyncio.run(mgr.close())
@@ -85,12 +98,14 @@ def test_128_concurrent_retrieves_equal_sequential_calls(gpu, long_timeout):
     SQ = [(np.sort(rng.choice(V, 40, replace=False)).astype(np.int32), np.abs(rng.standard_normal(40)).astype(np.float32))
           for _ in range(nq)]
     results = {}
-    for coalesce in (False, True):
+    for coalesce, one_round in ((False, False), (True, False), (True, True)):
         initialize_caches()
         mgr = MilvusIndexManager(semantic_dim=d, sparse_dim=V, dtype="float16", enable_domain=False, coalesce=coalesce)
         mgr.add_rows(X, (ptr, idx, val), chunk_index=(np.arange(n) % 10).tolist())
         mgr.finalize()
         mgr.embedding_generator = TableGen(Q, SQ)
+        if not one_round:
+            mgr.hybrid_search = None
         retr = HybridRetriever(mgr, RetrievalConfig(top_k=20))
 
         async def sequential():
@@ -104,13 +119,15 @@ def test_128_concurrent_retrieves_equal_sequential_calls(gpu, long_timeout):
         try:
             if coalesce:
                 outs = asyncio.run(concurrent())
-                results["concurrent"] = [_strip(o) for o in outs[:nq]]
-                results["filtered"] = [_strip(o) for o in outs[nq:]]
+                tag = "one_round" if one_round else "concurrent"
+                results[tag] = [_strip(o) for o in outs[:nq]]
+                results[tag + "_filtered"] = [_strip(o) for o in outs[nq:]]
                 st = dict(mgr._front.stats)
                 assert st["dense_launches"] + st["sparse_launches"] <= (2 * (nq + nq // 4)) // 4, st   # >= 4 queries per launch
                 assert st["max_batch_seen"] >= 16, st
+                assert (st["hybrid_launches"] > 0) == one_round and (st["fuse_launches"] == 0 or not one_round or st["redone_unproven"] > 0)
                 seq2 = asyncio.run(sequential())          # the front also serves one caller at a time
-                assert [_strip(o) for o in seq2] == results["concurrent"]
+                assert [_strip(o) for o in seq2] == results[tag]
             else:
                 results["sequential"] = [_strip(o) for o in asyncio.run(sequential())]
 
@@ -122,8 +139,58 @@ def test_128_concurrent_retrieves_equal_sequential_calls(gpu, long_timeout):
             asyncio.run(mgr.close())
     assert all(len(r) == 20 for r in results["sequential"])
     assert results["concurrent"] == results["sequential"]
-    assert results["filtered"] == results["filtered_sequential"]
-    assert all(ci < 5 for r in results["filtered"] for (_, _, _, ci) in r)
+    assert results["concurrent_filtered"] == results["filtered_sequential"]
+    assert results["one_round"] == results["sequential"]
+    assert results["one_round_filtered"] == results["filtered_sequential"]
+    assert all(r[3] < 5 for lst in results["one_round_filtered"] for r in lst)
+
+
+def test_one_round_requests_with_other_profiles_weights_and_a_bad_query(gpu, long_timeout):
+    """What the one-round path must hand to the general path or key apart: a weight adapter (its own engine per weight
+    pair), a profile with MMR (needs the whole fused list), a malformed sparse query inside a batch (that retrieve()
+    degrades to its dense hits, the others are untouched), an empty sparse query."""
+    from advanced_rag.embedding_cache import initialize_caches
+    rng = np.random.default_rng(11)
+    n, d, V, nq = 20000, 64, 500, 24
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    idx = np.sort(np.argpartition(rng.random((n, V)), 9, axis=1)[:, :10], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * 10)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    SQ = [(np.sort(rng.choice(V, 12, replace=False)).astype(np.int32), np.abs(rng.standard_normal(12)).astype(np.float32))
+          for _ in range(nq)]
+    SQ[3] = (np.array([7, 7, 9], np.int32), np.array([1.0, 0.5, 0.25], np.float32))     # duplicate index: refused
+    SQ[4] = (np.zeros(0, np.int32), np.zeros(0, np.float32))                            # no terms at all
+    outs = {}
+    for one_round in (False, True):
+        initialize_caches()
+        mgr = MilvusIndexManager(semantic_dim=d, sparse_dim=V, dtype="float32", enable_domain=False)
+        mgr.add_rows(X, (np.arange(n + 1, dtype=np.int64) * 10, idx, val), chunk_index=(np.arange(n) % 10).tolist())
+        mgr.finalize()
+        mgr.embedding_generator = TableGen(Q, SQ)
+        if not one_round:
+            mgr.hybrid_search = None
+        retr = HybridRetriever(mgr, RetrievalConfig(top_k=10), weight_adapter=lambda q: (0.5, 0.5) if int(q[1:]) % 2 else (0.9, 0.2))
+
+        async def go():
+            # (concurrent requests share the retriever's active profile and adapted weights, as in the reference: only
+            # the shape of the answers is checked here)
+            plain = [retr.retrieve(f"q{i}", profile_hint="default") for i in range(nq)]
+            return await asyncio.gather(*plain)
+
+        hints = ("default", "faq", "troubleshooting")    # top_k 10 / 10 / 30 with MMR
+        try:
+            # the adapter rewrites the shared config per request (as the reference does): sequential calls, so that both
+            # paths see the same weights for the same query
+            seq = [asyncio.run(retr.retrieve(f"q{i}", profile_hint=hints[i % 3])) for i in range(nq)]
+            outs[one_round] = [_strip(o) for o in seq]
+            conc = asyncio.run(go())
+            assert [len(o) for o in conc] == [10] * nq
+            if one_round:
+                assert mgr._front.stats["hybrid_launches"] > 0
+        finally:
+            asyncio.run(mgr.close())
+    assert outs[True] == outs[False]
+    assert all(m == "semantic" for r in outs[True][3] for m in [r[4]]) and len(outs[True][3]) == 10   # dense hits only
 
 
 def test_a_bad_request_fails_alone(gpu, long_timeout):
