@@ -407,7 +407,6 @@ hipError_t launch_scan_bigq_g(const hr_index* h, hipStream_t s, const chunk_t* q
 // contraction to the register-resident pass where both apply
 int g_dense_kernels = 0;
 int g_sparse_rpb = 0;     // HR_DEBUG_SPARSE_RPB: doc ranges per sparse-scan block (0 = by shard size)
-int g_sparse_xcd = 0;     // HR_DEBUG_SPARSE_XCD: XCDs that share a chunk of ranges in the sparse scan (0 = by shape; 1, 2, 4; 8 = the plain 2-D grid)
 int g_group_rows = 0;     // HR_DEBUG_GROUP_ROWS: candidate-group size of handles created from now on (0 = by shard size)
 bool qreg_supported(const hr_index* h) {
     return !(g_dense_kernels & 1) && h->dtype == HR_F16 && h->KT == 24;
@@ -793,30 +792,13 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     }
     if (phases & PHASE_SCAN) {
         Span sp(h, s, PH_SSCAN);
-        int rpb = sparse_ranges_per_block(h, B);
-        // XCD-aware grid (sparse.h): the chunks of ranges dealt over groups of S XCDs, each group walking its chunks with
-        // all the queries of the batch.  Measured (B = 128): 10M docs Zipf -12 % in the pipeline, uniform +-0; 1.25M docs
-        // (77 ranges, chunks of 3) +5 % -> large shards only, and batches with several queries per XCD.
-        int S = g_sparse_xcd;   // 0 = by shape, 8 = the plain 2-D grid, 1 / 2 / 4 = forced
-        if (S == 0) S = (h->n_ranges >= 256 && B >= 16 && h->scan_cus == 0) ? 2 : 8;
-        if (S != 8) {
-            const int64_t n_chunks = (h->n_ranges + rpb - 1) / rpb;       // what the 2-D grid would have
-            const int NG = 8 / S;
-            const int64_t per_g = (n_chunks + NG - 1) / NG;               // chunks per group of S XCDs
-            const int64_t blocks = 8 * per_g * (int64_t)((B + S - 1) / S);
-            hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)blocks), dim3(kScanThreads), 0, s,
-                               h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
-                               ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
-                               ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, -(int)per_g,
-                               h->idle_post.as<uint32_t>(), ws->gmax.as<float>(), B, S);
-        } else {
-            const unsigned chunks = (unsigned)((h->n_ranges + rpb - 1) / rpb);
-            hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)B, chunks), dim3(kScanThreads), 0, s,
-                               h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
-                               ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
-                               ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, rpb,
-                               h->idle_post.as<uint32_t>(), ws->gmax.as<float>(), 0, 0);
-        }
+        const int rpb = sparse_ranges_per_block(h, B);
+        const unsigned chunks = (unsigned)((h->n_ranges + rpb - 1) / rpb);
+        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)B, chunks), dim3(kScanThreads), 0, s,
+                           h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
+                           ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
+                           ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, rpb,
+                           h->idle_post.as<uint32_t>(), ws->gmax.as<float>());
         HIP_TRY(h, hipGetLastError());
     }
     if (!(phases & PHASE_FINISH)) return HR_OK;
@@ -1806,11 +1788,6 @@ int hr_debug_option(hr_index* h, int key, int value) {
         case HR_DEBUG_GROUP_ROWS:
             if (value != 0 && value != 16 && value != 64) return fail(h, HR_EINVAL, "group rows must be 0, 16 or 64");
             g_group_rows = value;
-            return HR_OK;
-        case HR_DEBUG_SPARSE_XCD:
-            if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
-                return fail(h, HR_EINVAL, "XCDs per chunk of ranges must be 0, 1, 2, 4 or 8");
-            g_sparse_xcd = value;
             return HR_OK;
         case HR_DEBUG_FAIL_NEXT_BUILD:
             if (!h) return fail(nullptr, HR_EINVAL, "null handle");

@@ -233,43 +233,20 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
     const uint32_t* __restrict__ post, const int32_t* __restrict__ pq_n, const int32_t* __restrict__ pq_idx,
     const float* __restrict__ pq_w, int stride, const float* __restrict__ q_scale,
     const uint8_t* __restrict__ rowmask, int64_t n_docs, int64_t n_groups, int group_docs, int64_t n_ranges,
-    int rpb, const uint32_t* __restrict__ idle_postings, float* __restrict__ gmax, int xcd_batch, int xcd_share) {
+    int rpb, const uint32_t* __restrict__ idle_postings, float* __restrict__ gmax) {
     constexpr int K = kScanK, NW = kScanWaves, DPT = kDocsPerThread;
     __shared__ int acc[kAccWords];
     __shared__ ScanTab tab[2];  // T(s) lives in tab[s & 1]
     __shared__ unsigned run_first[kScanTermChunk], run_lo[kScanTermChunk], run_hi[kScanTermChunk];  // wave 0's scratch for long runs
     __shared__ float run_w[kScanTermChunk];
-    int qi;
-    int64_t r0;
-    int n_r;
-    if (xcd_share > 0) {
-        // XCD-aware form (1-D grid).  Workgroup L runs on XCD L % 8 (strict round-robin dispatch, also when the grid
-        // oversubscribes the chip: tests/probes/xcd_dispatch_census.hip) and every XCD has its own L2.  The chunks of
-        // ranges are dealt round-robin to the 8 / S groups of S = xcd_share XCDs; a group walks its chunks one after
-        // the other with ALL the batch's queries (query q of a chunk on XCD q % S of the group).  With the 2-D grid
-        // (x = query) the 128 queries of a chunk were spread over all eight L2s; with S = 2 a chunk is seen by two: the
-        // run-bound rows are fetched a quarter as often (S = 1, uniform postings: fetch 1.13 -> 1.02 of the algorithmic
-        // bytes) and the frequent terms that most queries of a Zipfian batch share reach fewer L2s at a time (10M docs,
-        // B = 128: Zipf 1.1 4.15 -> 3.37 ms, uniform 0.750 -> 0.745 ms; S = 1: 3.46 / 0.76-0.77, S = 4: 3.40 / 0.757).
-        // -rpb = chunks per group; chunk sizes differ by at most one range.
-        const unsigned L = blockIdx.x;
-        const int x = (int)(L & 7u), j = (int)(L >> 3);
-        const int S = xcd_share, NG = 8 / S;
-        const int g = x / S, m = x - g * S;
-        const int per_q = (xcd_batch + S - 1) / S;     // queries per XCD of a chunk
-        const int cc = j / per_q;
-        qi = (j - cc * per_q) * S + m;
-        if (qi >= xcd_batch) return;                   // the whole block: nothing has been synchronised yet
-        const int64_t n_chunks = NG * (int64_t)(-rpb), base = n_ranges / n_chunks, extra = n_ranges % n_chunks;
-        const int64_t y = (int64_t)cc * NG + g;
-        r0 = base * y + min(y, extra);
-        n_r = (int)(base + (y < extra ? 1 : 0));
-        if (n_r == 0) return;
-    } else {
-        qi = blockIdx.x;
-        r0 = (int64_t)blockIdx.y * rpb;
-        n_r = (int)min((int64_t)rpb, n_ranges - r0);
-    }
+    // Block (x, y) = chunk y of query (x + y) mod B.  Workgroups go to the eight XCDs strictly round-robin in linear order
+    // (tests/probes/xcd_dispatch_census.hip: workgroup L runs on XCD L % 8, also when the grid oversubscribes the chip) and
+    // B is usually a multiple of 8: without the rotation XCD i would run queries i, i + 8, ... of EVERY chunk, and the XCD
+    // that drew the expensive queries (frequent terms, long queries) would finish last — Zipfian postings at 10M docs,
+    // B = 128: 4.15 ms without the rotation, 3.38 ms with it (uniform postings: 0.75 ms either way).
+    const int qi = (int)((blockIdx.x + blockIdx.y) % gridDim.x);
+    const int64_t r0 = (int64_t)blockIdx.y * rpb;
+    const int n_r = (int)min((int64_t)rpb, n_ranges - r0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {

@@ -236,8 +236,6 @@ def main():
     ap.add_argument("--group-rows", type=int, choices=(0, 16, 64), default=0, help="rows per candidate group (0 = by shard size)")
     ap.add_argument("--dense-kernel-mask", type=int, default=0,
                     help="hr_debug_option(HR_DEBUG_DENSE_KERNELS) bit mask for A/B runs")
-    ap.add_argument("--sparse-xcd", type=int, choices=(0, 1, 2, 4, 8), default=0,
-                    help="XCDs that share a chunk of doc ranges in the sparse scan's grid (0 = by shape, 8 = the plain grid)")
     ap.add_argument("--finish-mode", choices=("auto", "chain", "fused"), default="auto",
                     help="finishing path: auto = fused kernel for batches that fill the chip, chain = five launches")
     args = ap.parse_args()
@@ -339,7 +337,6 @@ def main():
     cfg = EngineConfig(top_k=args.top_k, use_sparse=use_sparse)
     n_fly = max(1, args.in_flight) if use_sparse else 1
     nat.debug_option(nat.HR_DEBUG_FINISH_MODE, {"auto": 0, "chain": 1, "fused": 2}[args.finish_mode])
-    nat.debug_option(nat.HR_DEBUG_SPARSE_XCD, args.sparse_xcd)
     sim = args.simulate_ranks if world == 1 else 0
     eng = PipelinedSearchEngine(h, cfg, device=str(dev), depth=n_fly, simulate_ranks=sim, light_cus=args.light_cus,
                                 prep_stream=args.prep_stream) if n_fly > 1 else \
@@ -651,7 +648,6 @@ def main():
                        "streams": ("heavy (scans) + light (finish, exchange, post)" + (" + prep (query preparation)" if args.prep_stream else "")
                                    + (f"; CU masks: {args.light_cus} CUs for light + prep, the rest for the scans" if args.light_cus else "; priorities only")) if n_fly > 1 else "one stream",
                        "finish": args.finish_mode, "group_rows": args.group_rows or "by shard size",
-                       **({"sparse_xcds_per_chunk": args.sparse_xcd} if args.sparse_xcd else {}),
                        **({"dense_kernel_mask": args.dense_kernel_mask} if args.dense_kernel_mask else {}),
                        **({"simulate_ranks": sim, "projection": f"per-rank step of a {N * sim}-row corpus on {sim} GPUs: the merge of {sim} lists per modality "
                            "runs on the finishing stream, the all-gather itself is NOT included"} if sim else {}),

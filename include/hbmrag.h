@@ -348,12 +348,9 @@ HR_API int hr_set_scan_cus(hr_index* h, int n_cus);
  * HR_DEBUG_SPARSE_RPB (process-wide): doc ranges one sparse-scan block walks (0 = by shard size).
  * HR_DEBUG_GROUP_ROWS (process-wide): rows per candidate group (16 or 64; 0 = by shard size) of handles created
  *   afterwards.
- * HR_DEBUG_SPARSE_XCD (process-wide): how many XCDs share a chunk of doc ranges in the sparse scan's grid — 1, 2 or 4
- *   (the chunks are dealt over groups of that many XCDs; a group walks its chunks with all the queries of the batch),
- *   8 = the plain (query, chunk) grid, 0 = by shape (2 for shards of 256+ ranges and batches of 16+ queries, else 8).
  * The library reads no environment variables. */
 enum { HR_DEBUG_FINISH_MODE = 1, HR_DEBUG_FAIL_NEXT_BUILD = 2, HR_DEBUG_DENSE_KERNELS = 3, HR_DEBUG_SPARSE_RPB = 4,
-       HR_DEBUG_GROUP_ROWS = 5, HR_DEBUG_SPARSE_XCD = 6 };
+       HR_DEBUG_GROUP_ROWS = 5 };
 HR_API int hr_debug_option(hr_index* h, int key, int value);
 
 /* ---- measurement hooks -------------------------------------------------------

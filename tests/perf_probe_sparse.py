@@ -12,7 +12,6 @@ from bench import sparse_block, sparse_block_zipf, zipf_queries, SPARSE_DIM, SPA
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2_500_000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 ZIPF = len(sys.argv) > 3 and sys.argv[3] == "zipf"   # Zipf(1.1) postings + 20-term queries (bench.py --sparse-dist zipf)
-XCD_MODES = [int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]   # HR_DEBUG_SPARSE_XCD values to time
 dev = torch.device("cuda:0")
 h = nat.ShardHandle(64, nat.HR_F16, nat.HR_METRIC_COSINE, SPARSE_DIM)
 blk = 250_000
@@ -37,20 +36,6 @@ h.set_profiling(2)
 def run():
     h.search_sparse_dev(d_ptr.data_ptr(), d_i.data_ptr(), d_v.data_ptr(), B, int(qi.shape[0]), int(mx), 40,
                         ids.data_ptr(), sc.data_ptr(), fl.data_ptr(), 0, st)
-ref_ids = None
-for mode in XCD_MODES:   # every grid form of the scan in the same process, on the same shard
-    nat.debug_option(nat.HR_DEBUG_SPARSE_XCD, mode)
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize(); h.kernel_ms()
-    for _ in range(10):
-        run()
-    torch.cuda.synchronize()
-    ms_ = h.kernel_ms()
-    same = "" if ref_ids is None else f"  lists identical to the first mode: {bool((ids.cpu() == ref_ids).all())}"
-    ref_ids = ids.cpu().clone() if ref_ids is None else ref_ids
-    print(f"docs {N} B {B} {'zipf' if ZIPF else 'uniform'} xcd mode {mode}: sparse_scan {ms_['sparse_scan'][0]:.3f} ms  exact {int(fl.sum())}/{B}{same}", flush=True)
-nat.debug_option(nat.HR_DEBUG_SPARSE_XCD, XCD_MODES[-1])
 for _ in range(3):
     run()
 torch.cuda.synchronize(); h.kernel_ms()

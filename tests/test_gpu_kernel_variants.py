@@ -1,7 +1,7 @@
 """Every dense scan kernel at every shape it can serve: hr_debug_option(HR_DEBUG_DENSE_KERNELS) takes kernels out of the
 selection so that the others step in (no register-resident 256-query pass -> the tiled contraction at D = 768 too; no
 tiled contraction -> two 128-query passes; ...), HR_DEBUG_SPARSE_RPB / HR_DEBUG_GROUP_ROWS pin the sparse scan's ranges
-per block and the candidate-group size, HR_DEBUG_SPARSE_XCD how many XCDs share a chunk of ranges in its grid.  Ids and score bits must match the oracle on every path, as on the defaults.
+per block and the candidate-group size.  Ids and score bits must match the oracle on every path, as on the defaults.
 (The library reads no environment variables; these hooks are process-wide and reset after each test.)"""
 import numpy as np
 import pytest
@@ -21,8 +21,7 @@ def options():
     def set_(key, value):
         nat.debug_option(key, value)
     yield set_
-    for key in (nat.HR_DEBUG_DENSE_KERNELS, nat.HR_DEBUG_SPARSE_RPB, nat.HR_DEBUG_GROUP_ROWS, nat.HR_DEBUG_FINISH_MODE,
-                nat.HR_DEBUG_SPARSE_XCD):
+    for key in (nat.HR_DEBUG_DENSE_KERNELS, nat.HR_DEBUG_SPARSE_RPB, nat.HR_DEBUG_GROUP_ROWS, nat.HR_DEBUG_FINISH_MODE):
         nat.debug_option(key, 0)
 
 
@@ -51,14 +50,10 @@ def test_dense_kernel_variants_match_the_oracle(gpu, options, mask):
         h.close()
 
 
-@pytest.mark.parametrize("rpb,group_rows,xcds", [(1, 64, 0), (3, 16, 0), (16, 0, 0), (1, 0, 1), (2, 16, 2), (3, 0, 4), (16, 64, 2),
-                                                 (0, 0, 8)])
-def test_sparse_scan_geometry_variants_match_the_oracle(gpu, options, rpb, group_rows, xcds):
-    """xcds = 1 / 2 / 4: the XCD-aware grid forced on a shard with only four ranges (chunks of one range, groups without a
-    chunk, XCDs whose query slots run past the batch: 70 queries over 4 XCDs); 8 = the plain (query, chunk) grid."""
+@pytest.mark.parametrize("rpb,group_rows", [(1, 64), (3, 16), (16, 0)])
+def test_sparse_scan_geometry_variants_match_the_oracle(gpu, options, rpb, group_rows):
     options(nat.HR_DEBUG_SPARSE_RPB, rpb)
     options(nat.HR_DEBUG_GROUP_ROWS, group_rows)
-    options(nat.HR_DEBUG_SPARSE_XCD, xcds)
     rng = np.random.default_rng(11)
     V, nd = 3000, 60000
     idx = [np.sort(rng.choice(V, size=rng.integers(1, 60), replace=False)).astype(np.int32) for _ in range(nd)]
