@@ -120,7 +120,7 @@ class _Layer(nn.Module):
         B, T, H = x.shape
         hd = H // self.heads
         qkv = self.qkv(x)
-        if lengths is not None and x.is_cuda and x.dtype == torch.float16 and hd == 32:
+        if lengths is not None and x.is_cuda and x.dtype == torch.float16 and hd == 32 and T <= 1024:
             # head dimension 32 on the GPU: the HIP attention kernel reads the fused projection as it stands and writes
             # the [tokens, hidden] layout the output projection wants — no permute / transpose copies, no SDPA
             qkv = qkv.contiguous()

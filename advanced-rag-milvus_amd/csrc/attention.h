@@ -4,16 +4,20 @@
 // layer on 2560 sequences x 128 tokens (15x its memory bound: a 32-wide head fills a quarter of a generic flash
 // tile), plus the permute / transpose copies around it.
 //
-// One block (4 waves) per (sequence, head, 128 queries); a wave owns 32 queries (two 16-wide tiles) and walks the keys
-// in chunks of 32 with an online softmax.  Everything a query needs stays in ITS lane column:
+// One block of NW waves per (sequence, head, 32 NW queries) — NW = 4 up to 128 tokens, 8 beyond; a wave owns 32 queries
+// (two 16-wide tiles) and walks the keys in chunks of 32 with an online softmax.  K and V of the (sequence, head) are
+// staged ONCE per block in LDS (K as it stands, V transposed into fragment order): with K fetched per wave from global
+// memory (the first form) every wave re-read all keys as 64-byte pieces 2 304 bytes apart and the kernel waited on those
+// loads (T = 512: 2.7 ms per layer against 0.4 ms of MFMA time).  Everything a query needs stays in ITS lane column:
 //   S^T[keys x queries] = K . Q^T     A = K rows (16 keys x 32 dims: ONE v_mfma_f32_16x16x32_f16 k-step),
 //                                     B = Q rows  -> lane (query = l & 15, g = l >> 4) holds keys 4g .. 4g+3 of a tile
 //   O^T[dims x queries] += V^T . P^T  A = V^T (16 dims x 32 keys), B = P^T: the lane's own eight probabilities of the
 //                                     chunk ARE its B fragment (k index j <-> key 4g+j of tile 0, 4g+j-4 of tile 1),
 //                                     so P never moves between lanes; V is staged once per block in LDS, transposed
 //                                     and in that same key order, so an A fragment is one ds_read_b128
-// and the running maximum / sum / output of a query are rescaled by a per-lane scalar.
-// K and Q fragments are 16-byte global loads (a key's / query's 32 dims are 64 contiguous bytes of the QKV row).
+// and the reference maximum / sum / output of a query are rescaled by a per-lane scalar — rarely (see the loop).
+// Q fragments are 16-byte global loads (a query's 32 dims are 64 contiguous bytes of the QKV row); a K fragment is one
+// conflict-free ds_read_b128 (a wave reads 16 keys x 64 bytes = 1 KiB contiguous).
 // Keys at or beyond the sequence's length (padding at the tail, as HashTokenizer.batch pads) get probability 0.
 #pragma once
 #include "common.h"
@@ -21,7 +25,7 @@
 namespace hbmrag {
 
 constexpr int kAttnHeadDim = 32;
-constexpr int kAttnQueriesPerBlock = 128;
+constexpr int kAttnMaxT = 1024;   // K + V of a (sequence, head) in LDS: 128 bytes per token
 
 __device__ inline float wave_col_max(float v) {   // over the four lane groups that share a query column
     v = fmaxf(v, __shfl_xor(v, 16));
@@ -29,33 +33,50 @@ __device__ inline float wave_col_max(float v) {   // over the four lane groups t
 }
 
 // qkv: [n_seq][T][3][heads][32] halves; lengths: [n_seq] valid tokens (null = T); out: [n_seq][T][heads * 32] halves.
-__global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __restrict__ qkv, const int32_t* __restrict__ lengths,
-                                                             _Float16* __restrict__ out, int T, int heads, float scale_log2e) {
-    extern __shared__ half8_t attn_vt[];   // [chunks][2 dim tiles][64 lanes] fragments of V^T
-    const int seq = blockIdx.x / heads, head = blockIdx.x % heads;
+//
+// Grid: 1-D, XCD-aware.  A head's Q / K / V piece of a token is 64 bytes, so a 128-byte line of the QKV buffer belongs to
+// TWO heads, and at T > 128 the blocks of one (sequence, head) all read the same K and V.  Workgroup L runs on XCD L % 8
+// (strict round-robin dispatch: tests/probes/xcd_dispatch_census.hip), each XCD with its own L2: the G = 2 x q-blocks
+// blocks of a head PAIR are given linear ids (P / 8) * 8 G + i * 8 + P % 8, i < G — consecutive launches on ONE XCD — so a
+// line is fetched from HBM once, not once per block that needs it.  (With (sequence x head, q-block) as a 2-D grid the two
+// heads of a line sat on different XCDs and the q-blocks of a head 30 720 workgroups apart: 2x the QKV bytes at T = 128,
+// up to 5x at T = 512.)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kernel(const _Float16* __restrict__ qkv,
+                                                                                  const int32_t* __restrict__ lengths,
+                                                                                  _Float16* __restrict__ out, int T, int heads,
+                                                                                  float scale_log2e, int n_qblocks,
+                                                                                  int64_t n_pairs) {
+    extern __shared__ half8_t attn_vt[];   // [chunks][2 dim tiles][64 lanes] fragments of V^T, then K: [chunks * 32 keys][4] pieces
+    const int G = 2 * n_qblocks;
+    const int64_t L = blockIdx.x;
+    const int64_t P = (L / (8 * G)) * 8 + (L & 7);        // head pair: sequence * ceil(heads / 2) + pair of the sequence
+    const int i_blk = (int)((L / 8) % G);
+    if (P >= n_pairs) return;
+    const int pairs_per_seq = (heads + 1) / 2;
+    const int seq = (int)(P / pairs_per_seq), head = 2 * (int)(P % pairs_per_seq) + i_blk / n_qblocks;
+    const int q_block = i_blk % n_qblocks;
+    if (head >= heads) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = lane & 15, g = lane >> 4;
     const int H = heads * kAttnHeadDim;
     const int len = lengths ? min(lengths[seq], T) : T;
     const int n_chunks = (T + 31) / 32;
     const _Float16* base = qkv + (int64_t)seq * T * 3 * H + head * kAttnHeadDim;   // + t * 3H (+ H for K, + 2H for V)
+    half8_t* ks = attn_vt + n_chunks * 2 * 64;
 
-    // Q and the first K fragments are requested before V is staged: three dependent round trips become two
-    const int q0 = blockIdx.y * kAttnQueriesPerBlock + wid * 32;
-    half8_t qf[2], kf[2], kn[2];
+    // Q is requested before K and V are staged
+    const int q0 = q_block * 32 * NW + wid * 32;
+    half8_t qf[2], kf[2];
     auto load_k = [&](int c, half8_t (&kfr)[2]) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const int key = min(32 * c + 16 * kt + col, T - 1);
-            kfr[kt] = *reinterpret_cast<const half8_t*>(base + (int64_t)key * 3 * H + H + 8 * g);
-        }
+        for (int kt = 0; kt < 2; ++kt) kfr[kt] = ks[(32 * c + 16 * kt + col) * 4 + (g ^ ((col >> 2) & 3))];
     };
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = min(q0 + 16 * qt + col, T - 1);
         qf[qt] = *reinterpret_cast<const half8_t*>(base + (int64_t)q * 3 * H + 8 * g);
     }
-    load_k(0, kf);
     // the softmax scale (x log2 e) goes into Q once — 8 multiplies per query tile instead of one per score; the
     // product is rounded to fp16 like Q itself (|scale| < 1: no overflow), well inside the kernel's fp16 tolerance
     const _Float16 qs = (_Float16)scale_log2e;
@@ -64,12 +85,17 @@ __global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __r
 #pragma unroll
         for (int i = 0; i < 8; ++i) qf[qt][i] *= qs;
 
-    // ---- stage V^T: thread takes (key, 8 dims) pieces; dim d of key k goes to fragment (chunk, d >> 4), lane (d & 15) + 16 g', slot j
+    // ---- stage K (as it stands) and V^T: thread takes (key, 8 dims) pieces; dim d of V's key k goes to fragment
+    // (chunk, d >> 4), lane (d & 15) + 16 g', slot j
     _Float16* vt = reinterpret_cast<_Float16*>(attn_vt);
-    for (int piece = threadIdx.x; piece < n_chunks * 32 * 4; piece += 256) {
+    for (int piece = threadIdx.x; piece < n_chunks * 32 * 4; piece += 64 * NW) {
         const int key = piece >> 2, e = piece & 3;
-        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < T) v = *reinterpret_cast<const half8_t*>(base + (int64_t)key * 3 * H + 2 * H + 8 * e);
+        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0}, kk8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < T) {
+            kk8 = *reinterpret_cast<const half8_t*>(base + (int64_t)key * 3 * H + H + 8 * e);
+            v = *reinterpret_cast<const half8_t*>(base + (int64_t)key * 3 * H + 2 * H + 8 * e);
+        }
+        ks[key * 4 + (e ^ ((key >> 2) & 3))] = kk8;   // pieces of a key rotated by key / 4: the 16 lanes of a fragment read hit 16 different bank groups
         const int c = key >> 5, kk = key & 31;
         const int gg = (kk & 15) >> 2, j = (kk & 3) + (kk >= 16 ? 4 : 0);
 #pragma unroll
@@ -90,14 +116,23 @@ __global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __r
         for (int dt = 0; dt < 2; ++dt) o[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     const int live_chunks = (len + 31) / 32;   // chunks beyond the sequence's length hold nothing but masked keys
+    // The softmax is what this kernel spends its time on (8 MFMAs per chunk against the vector work of 16 scores per lane),
+    // so the common path is kept to: scores straight out of the MFMA already minus the reference maximum (it is the
+    // accumulator's initial value), 16 raw v_exp_f32, 8 pack conversions, the partial sums.  The reference maximum m[qt] of
+    // a query is NOT the running maximum: it is only moved (and the sum and the output rescaled — a branch the whole wave
+    // takes) when some score exceeds it by about 2^8, so every probability stays below 2^8 — well inside fp16 — and the
+    // sums are the same sums up to rounding.  The first chunk always takes the branch (m = true maximum of the chunk);
+    // maxima are formed only there.
     for (int c = 0; c < live_chunks; ++c) {
-        load_k(c + 1 < live_chunks ? c + 1 : c, kn);
-        f32x4_t s[2][2];   // [key tile][query tile]
+        load_k(c, kf);
+        f32x4_t s[2][2];   // [key tile][query tile]: score - m[qt]
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+        for (int qt = 0; qt < 2; ++qt) {
+            const float neg = c == 0 ? 0.f : -m[qt];
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt)
-                s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf[qt], (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            for (int kt = 0; kt < 2; ++kt)
+                s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf[qt], (f32x4_t){neg, neg, neg, neg}, 0, 0, 0);
+        }
         // keys at or beyond the length exist only in the sequence's last live chunk: the mask costs nothing elsewhere
         if (32 * c + 32 > len) {
 #pragma unroll
@@ -108,34 +143,53 @@ __global__ __launch_bounds__(256) void attention_hd32_kernel(const _Float16* __r
                     for (int r = 0; r < 4; ++r)
                         if (32 * c + 16 * kt + 4 * g + r >= len) s[kt][qt][r] = -__builtin_inff();
         }
+        float e[2][8], sum8[2];
+        auto exps = [&]() {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) e[qt][4 * kt + r] = __builtin_amdgcn_exp2f(s[kt][qt][r]);
+                sum8[qt] = ((e[qt][0] + e[qt][1]) + (e[qt][2] + e[qt][3])) + ((e[qt][4] + e[qt][5]) + (e[qt][6] + e[qt][7]));
+            }
+        };
+        exps();
+        // a score more than the gap above its reference maximum shows in the lane's partial sum (every term is >= 0): no
+        // maxima are formed on the common path.  (A sum can pass 2^gap without such a score — eight scores just below the
+        // gap: the branch is then taken needlessly, which is harmless.)
+        if (c == 0 || __any(fmaxf(sum8[0], sum8[1]) > 256.f)) {
+            // move the reference maxima to the true maxima seen so far (key 0 is always valid: finite from chunk 0 on)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                                       fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+                const float up = fmaxf(wave_col_max(mx), c == 0 ? -__builtin_inff() : 0.f);   // relative to m[qt] (chunk 0: absolute)
+                const float alpha = c == 0 ? 0.f : __builtin_amdgcn_exp2f(-up);
+                m[qt] = c == 0 ? up : m[qt] + up;
+                l[qt] *= alpha;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[kt][qt][r] -= up;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
+            }
+            exps();
+        }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
-                             fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
-            // key 0 is always valid (length >= 1), so the running maximum is finite from the first chunk on
-            const float m_new = fmaxf(m[qt], wave_col_max(mx));
-            const float alpha = exp2f(m[qt] - m_new);   // first chunk: exp2(-inf) = 0 times a zero accumulator
-            m[qt] = m_new;
-            float e[8];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) e[4 * kt + r] = exp2f(s[kt][qt][r] - m_new);
-            const float sum = ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
             typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
             union { half8_t v; fp16x2_t h2[4]; } p;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) p.h2[i] = __builtin_amdgcn_cvt_pkrtz(e[2 * i], e[2 * i + 1]);
-            l[qt] = l[qt] * alpha + sum;
+            for (int i = 0; i < 4; ++i) p.h2[i] = __builtin_amdgcn_cvt_pkrtz(e[qt][2 * i], e[qt][2 * i + 1]);
+            l[qt] += sum8[qt];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
+            for (int dt = 0; dt < 2; ++dt)
                 o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_vt[(c * 2 + dt) * 64 + lane], p.v, o[dt][qt], 0, 0, 0);
-            }
         }
-        kf[0] = kn[0];
-        kf[1] = kn[1];
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {

@@ -1843,22 +1843,34 @@ int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_ou
                          int head_dim, float scale, void* stream) {
     if (n_seq < 0 || T <= 0 || heads <= 0) return fail(nullptr, HR_EINVAL, "bad attention sizes");
     if (head_dim != kAttnHeadDim) return fail(nullptr, HR_ELIMIT, "this attention kernel serves head dimension %d only (got %d)", kAttnHeadDim, head_dim);
-    if (T > 4096) return fail(nullptr, HR_ELIMIT, "sequence length %d exceeds 4096", T);
+    if (T > kAttnMaxT) return fail(nullptr, HR_ELIMIT, "sequence length %d exceeds %d", T, kAttnMaxT);
     if (!d_qkv || !d_out) return fail(nullptr, HR_EINVAL, "null buffer");
     if (((uintptr_t)d_qkv | (uintptr_t)d_out) & 15) return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
     if (n_seq == 0) return HR_OK;
     if (n_seq * heads > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many (sequence, head) pairs");
     const int n_chunks = (T + 31) / 32;
-    const size_t lds = (size_t)n_chunks * 2 * 64 * sizeof(half8_t);
+    const size_t lds = (size_t)n_chunks * 32 * 128;   // K and V^T of a (sequence, head)
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e0 = hipFuncSetAttribute((const void*)attention_hd32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        hipError_t e0 = hipFuncSetAttribute((const void*)attention_hd32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnMaxT * 128);
+        if (e0 == hipSuccess)
+            e0 = hipFuncSetAttribute((const void*)attention_hd32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnMaxT * 128);
         if (e0 != hipSuccess) return fail(nullptr, HR_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e0));
         attr_set = true;
     }
-    const dim3 grid((unsigned)(n_seq * heads), (unsigned)((T + kAttnQueriesPerBlock - 1) / kAttnQueriesPerBlock));
-    hipLaunchKernelGGL(attention_hd32_kernel, grid, dim3(256), lds, (hipStream_t)stream, (const _Float16*)d_qkv, d_lengths,
-                       (_Float16*)d_out, T, heads, scale * 1.4426950408889634f);
+    const int NW = T <= 128 ? 4 : 8;                                   // waves (x 32 queries) per block
+    const int n_qblocks = (T + 32 * NW - 1) / (32 * NW);
+    const int64_t n_pairs = n_seq * ((heads + 1) / 2);                 // head pairs: the blocks of a pair share an XCD
+    const int64_t n_blocks = ((n_pairs + 7) / 8) * 8 * 2 * n_qblocks;
+    if (n_blocks > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many attention blocks");
+    if (NW == 4)
+        hipLaunchKernelGGL(attention_hd32_kernel<4>, dim3((unsigned)n_blocks), dim3(256), lds, (hipStream_t)stream,
+                           (const _Float16*)d_qkv, d_lengths, (_Float16*)d_out, T, heads, scale * 1.4426950408889634f,
+                           n_qblocks, n_pairs);
+    else
+        hipLaunchKernelGGL(attention_hd32_kernel<8>, dim3((unsigned)n_blocks), dim3(512), lds, (hipStream_t)stream,
+                           (const _Float16*)d_qkv, d_lengths, (_Float16*)d_out, T, heads, scale * 1.4426950408889634f,
+                           n_qblocks, n_pairs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, HR_EHIP, "attention_hd32_kernel: %s", hipGetErrorString(e));
     return HR_OK;

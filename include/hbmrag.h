@@ -320,7 +320,8 @@ HR_API int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, con
 /* Self-attention for head dimension 32, from the fused QKV projection's output to the layout the output projection
  * reads (the PyTorch SDPA call plus the permute / transpose copies around it, in one kernel):
  *   d_qkv [n_seq][T][3][heads][32] fp16, d_lengths[n_seq] valid tokens per sequence (padding at the tail; NULL = T),
- *   d_out [n_seq][T][heads * 32] fp16 = softmax(scale * Q K^T, keys < length) V per head, fp32 accumulation. */
+ *   d_out [n_seq][T][heads * 32] fp16 = softmax(scale * Q K^T, keys < length) V per head, fp32 accumulation.
+ * T <= 1024 (K and V of a (sequence, head) are staged in LDS); HR_ELIMIT beyond. */
 HR_API int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out, int64_t n_seq, int T, int heads,
                          int head_dim, float scale, void* stream);
 

@@ -116,13 +116,19 @@ def test_128_concurrent_retrieves_equal_sequential_calls(gpu, long_timeout):
             filtered = [retr.retrieve(f"q{i}", filters={"chunk_index": {"$lt": 5}}, profile_hint="default") for i in range(0, nq, 4)]
             return await asyncio.gather(*plain, *filtered)
 
+        async def wide():   # top_k = 100: lists of 200 per modality (k' = 200 of HR_MAX_TOPK = 256), 304 candidate groups
+            r100 = HybridRetriever(mgr, RetrievalConfig(top_k=100))
+            return await asyncio.gather(*[r100.retrieve(f"q{i}", profile_hint="default") for i in range(0, nq, 16)])
+
         try:
+            results.setdefault("wide", {})[(coalesce, one_round)] = [_strip(o) for o in asyncio.run(wide())]
             if coalesce:
+                st0 = dict(mgr._front.stats)
                 outs = asyncio.run(concurrent())
                 tag = "one_round" if one_round else "concurrent"
                 results[tag] = [_strip(o) for o in outs[:nq]]
                 results[tag + "_filtered"] = [_strip(o) for o in outs[nq:]]
-                st = dict(mgr._front.stats)
+                st = {k: (v - st0[k] if k != "max_batch_seen" else v) for k, v in mgr._front.stats.items()}
                 assert st["dense_launches"] + st["sparse_launches"] <= (2 * (nq + nq // 4)) // 4, st   # >= 4 queries per launch
                 assert st["max_batch_seen"] >= 16, st
                 assert (st["hybrid_launches"] > 0) == one_round and (st["fuse_launches"] == 0 or not one_round or st["redone_unproven"] > 0)
@@ -138,6 +144,9 @@ def test_128_concurrent_retrieves_equal_sequential_calls(gpu, long_timeout):
         finally:
             asyncio.run(mgr.close())
     assert all(len(r) == 20 for r in results["sequential"])
+    wide = results["wide"]
+    assert all(len(r) == 100 for r in wide[(False, False)])
+    assert wide[(True, False)] == wide[(False, False)] and wide[(True, True)] == wide[(False, False)]
     assert results["concurrent"] == results["sequential"]
     assert results["concurrent_filtered"] == results["filtered_sequential"]
     assert results["one_round"] == results["sequential"]
