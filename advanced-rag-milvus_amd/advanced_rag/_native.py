@@ -103,6 +103,9 @@ _SIGNATURES = {
                                             _c.c_int, _c.c_float, _c.c_void_p]),
     "hr_attention_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_float, _c.c_void_p]),
+    "hr_attention_rows_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
+                                             _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
+                                             _c.c_void_p]),
     "hr_set_profiling": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "hr_last_kernel_ms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int]),
 }
@@ -509,6 +512,18 @@ def attention_f16_dev(d_qkv: int, d_lengths: int, d_out: int, n_seq: int, T: int
     L = load_library()
     rc = L.hr_attention_f16_dev(_vp(d_qkv), _vp(d_lengths) if d_lengths else None, _vp(d_out), n_seq, T, heads, head_dim,
                                 float(scale), _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def attention_rows_f16_dev(d_q: int, q_seq_stride: int, q_token_stride: int, d_k: int, d_v: int, kv_seq_stride: int,
+                           kv_token_stride: int, d_lengths: int, d_out: int, n_seq: int, T: int, n_queries: int, heads: int,
+                           head_dim: int, scale: float, stream: int = 0):
+    """The attention kernel with operands by pointer and stride (halves): the first n_queries tokens are the queries."""
+    L = load_library()
+    rc = L.hr_attention_rows_f16_dev(_vp(d_q), q_seq_stride, q_token_stride, _vp(d_k), _vp(d_v), kv_seq_stride, kv_token_stride,
+                                     _vp(d_lengths) if d_lengths else None, _vp(d_out), n_seq, T, n_queries, heads, head_dim,
+                                     float(scale), _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
 

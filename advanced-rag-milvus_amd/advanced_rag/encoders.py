@@ -133,6 +133,34 @@ class _Layer(nn.Module):
         x = add_layer_norm(x, self.out(a), self.ln1)  # post-LN, as BERT
         return add_layer_norm(x, self.down(self._ffn_up(x)), self.ln2)
 
+    def forward_first_token(self, x, mask, lengths=None):
+        """The LAST layer of a model whose head reads token 0 only (the cross-encoder's relevance head reads [CLS]:
+        reference retrieval.py:651-685 hands the pairs to `CrossEncoder.predict`, whose classifier sits on the pooled
+        first token): keys and values of every token, and everything else — the query projection, the attention row,
+        the output projection, both LayerNorms, the FFN — for token 0 of each sequence alone.  The same arithmetic on
+        the rows that reach the output; 10/12 of the layer's GEMM work is for rows nothing reads.  x: [B, T, H] ->
+        [B, 1, H]."""
+        B, T, H = x.shape
+        hd = H // self.heads
+        W, b = self.qkv.weight, self.qkv.bias
+        kv = F.linear(x, W[H:], b[H:])                                                  # [B, T, 2, heads, hd]
+        q = F.linear(x[:, 0], W[:H], b[:H])                                             # [B, heads, hd]
+        if lengths is not None and x.is_cuda and x.dtype == torch.float16 and hd == 32 and T <= 1024:
+            # the HIP attention kernel with ONE query row per sequence against the K / V buffer (hr_attention_rows_f16_dev)
+            kv, q = kv.contiguous(), q.contiguous()
+            a = torch.empty((B, 1, H), dtype=x.dtype, device=x.device)
+            _native.attention_rows_f16_dev(q.data_ptr(), H, 0, kv.data_ptr(), kv.data_ptr() + 2 * H, T * 2 * H, 2 * H,
+                                           lengths.data_ptr(), a.data_ptr(), B, T, 1, self.heads, hd, hd ** -0.5,
+                                           torch.cuda.current_stream(x.device).cuda_stream)
+        else:
+            kv = kv.view(B, T, 2, self.heads, hd)
+            k, v = kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3)     # [B, heads, T, hd] views
+            s = torch.matmul(q.view(B, self.heads, 1, hd), k.transpose(-1, -2)).float() * (hd ** -0.5)   # [B, heads, 1, T]
+            s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+            a = torch.matmul(torch.softmax(s, dim=-1).to(x.dtype), v).reshape(B, 1, H)
+        x0 = add_layer_norm(x[:, :1], self.out(a), self.ln1)
+        return add_layer_norm(x0, self.down(self._ffn_up(x0)), self.ln2)
+
     def _ffn_up(self, x):
         if self.gelu != "tanh":
             return F.gelu(self.up(x))
@@ -152,15 +180,20 @@ class BertEncoder(nn.Module):
         self.ln = nn.LayerNorm(c.hidden, eps=c.eps)
         self.layers = nn.ModuleList(_Layer(c) for _ in range(c.layers))
 
-    def forward(self, ids, types, mask):
+    def forward(self, ids, types, mask, first_token_only: bool = False):
+        """-> hidden states [B, T, H]; with first_token_only, [B, 1, H]: the last layer computes token 0 alone
+        (_Layer.forward_first_token) — for heads that read nothing else."""
         T = ids.shape[1]
         x = add_layer_norm(self.word(ids) + self.pos(torch.arange(T, device=ids.device))[None], self.seg(types), self.ln)
         bias = torch.zeros(mask.shape, dtype=x.dtype, device=x.device).masked_fill(~mask, float("-inf"))[:, None, None, :]
         # valid tokens per sequence for the HIP attention kernel: padding sits at the tail (HashTokenizer.batch), so the
         # key mask is "position < length"
         lengths = mask.sum(dim=1).to(torch.int32) if x.is_cuda and x.dtype == torch.float16 else None
-        for layer in self.layers:
+        n_full = len(self.layers) - (1 if first_token_only else 0)
+        for layer in self.layers[:n_full]:
             x = layer(x, bias, lengths)
+        if first_token_only:
+            x = self.layers[-1].forward_first_token(x, mask, lengths)
         return x
 
 
@@ -326,8 +359,10 @@ class _CrossModule(nn.Module):
         self.encoder = BertEncoder(c)
         self.head = nn.Linear(c.hidden, 1)
 
-    def forward(self, ids, types, mask):
-        return self.head(self.encoder(ids, types, mask)[:, 0]).squeeze(-1).float()
+    def forward(self, ids, types, mask, all_tokens_last_layer: bool = False):
+        """Relevance logit per pair from token 0.  The last layer is computed for token 0 only (what the head reads);
+        all_tokens_last_layer=True runs it over every token, as a generic encoder would — the same logits (tests)."""
+        return self.head(self.encoder(ids, types, mask, first_token_only=not all_tokens_last_layer)[:, 0]).squeeze(-1).float()
 
 
 class CrossEncoderModel(_Base):
@@ -350,7 +385,14 @@ class CrossEncoderModel(_Base):
     def predict(self, pairs: Sequence[Tuple[str, str]]) -> np.ndarray:
         return self.predict_to_device(list(pairs)).cpu().numpy()
 
-    def flops_per_pair(self, seq_len: int) -> float:
+    def flops_per_pair(self, seq_len: int, executed: bool = True) -> float:
+        """Arithmetic of one pair's forward: per token and layer 8 H^2 + 4 H I for the projections and the FFN, plus
+        4 T H per token for the attention products.  executed=True (what `predict` runs): the last layer computes keys
+        and values for every token and the rest for token 0 only; executed=False: every layer over every token."""
         c = self.config
-        per_layer = 2 * seq_len * (4 * c.hidden * c.hidden + 2 * c.hidden * c.intermediate) + 4 * seq_len * seq_len * c.hidden
-        return float(c.layers * per_layer)
+        H, I, T = c.hidden, c.intermediate, seq_len
+        per_layer = 2 * T * (4 * H * H + 2 * H * I) + 4 * T * T * H
+        if not executed:
+            return float(c.layers * per_layer)
+        last = 2 * T * (2 * H * H) + 2 * (2 * H * H + 2 * H * I) + 4 * T * H
+        return float((c.layers - 1) * per_layer + last)

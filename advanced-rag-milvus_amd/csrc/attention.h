@@ -32,7 +32,10 @@ __device__ inline float wave_col_max(float v) {   // over the four lane groups t
     return fmaxf(v, __shfl_xor(v, 32));
 }
 
-// qkv: [n_seq][T][3][heads][32] halves; lengths: [n_seq] valid tokens (null = T); out: [n_seq][T][heads * 32] halves.
+// Operands by pointer and stride (AttnArgs): the fused QKV buffer [n_seq][T][3][heads][32] of an encoder layer, or separate
+// query rows and a KV buffer (the cross-encoder's last layer: ONE query row per sequence against [n_seq][T][2][heads][32]).
+// lengths: [n_seq] valid keys (null = T); the first n_queries tokens of a sequence are its queries;
+// out: [n_seq][n_queries][heads * 32] halves.
 //
 // Grid: 1-D, XCD-aware.  A head's Q / K / V piece of a token is 64 bytes, so a 128-byte line of the QKV buffer belongs to
 // TWO heads, and at T > 128 the blocks of one (sequence, head) all read the same K and V.  Workgroup L runs on XCD L % 8
@@ -41,12 +44,25 @@ __device__ inline float wave_col_max(float v) {   // over the four lane groups t
 // line is fetched from HBM once, not once per block that needs it.  (With (sequence x head, q-block) as a 2-D grid the two
 // heads of a line sat on different XCDs and the q-blocks of a head 30 720 workgroups apart: 2x the QKV bytes at T = 128,
 // up to 5x at T = 512.)
+struct AttnArgs {
+    const _Float16* q;   // query rows: q + seq * q_seq + token * q_tok + head * 32
+    const _Float16* k;   // key rows:   k + seq * kv_seq + token * kv_tok + head * 32 (v likewise)
+    const _Float16* v;
+    _Float16* out;       // out + (seq * n_queries + token) * heads * 32 + head * 32
+    const int32_t* lengths;
+    int64_t q_seq, q_tok, kv_seq, kv_tok;   // strides in halves
+    int T, n_queries, heads, n_qblocks;     // keys per sequence; the first n_queries tokens are the queries
+    int64_t n_pairs;
+    float scale_log2e;
+};
+
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kernel(const _Float16* __restrict__ qkv,
-                                                                                  const int32_t* __restrict__ lengths,
-                                                                                  _Float16* __restrict__ out, int T, int heads,
-                                                                                  float scale_log2e, int n_qblocks,
-                                                                                  int64_t n_pairs) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kernel(AttnArgs a) {
+    const int32_t* __restrict__ lengths = a.lengths;
+    _Float16* __restrict__ out = a.out;
+    const int T = a.T, heads = a.heads, n_qblocks = a.n_qblocks;
+    const int64_t n_pairs = a.n_pairs;
+    const float scale_log2e = a.scale_log2e;
     extern __shared__ half8_t attn_vt[];   // [chunks][2 dim tiles][64 lanes] fragments of V^T, then K: [chunks * 32 keys][4] pieces
     const int G = 2 * n_qblocks;
     const int64_t L = blockIdx.x;
@@ -62,7 +78,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
     const int H = heads * kAttnHeadDim;
     const int len = lengths ? min(lengths[seq], T) : T;
     const int n_chunks = (T + 31) / 32;
-    const _Float16* base = qkv + (int64_t)seq * T * 3 * H + head * kAttnHeadDim;   // + t * 3H (+ H for K, + 2H for V)
+    const _Float16* qb = a.q + seq * a.q_seq + head * kAttnHeadDim;
+    const _Float16* kb = a.k + seq * a.kv_seq + head * kAttnHeadDim;
+    const _Float16* vb = a.v + seq * a.kv_seq + head * kAttnHeadDim;
+    const int NQ = a.n_queries;
     half8_t* ks = attn_vt + n_chunks * 2 * 64;
 
     // Q is requested before K and V are staged
@@ -74,8 +93,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
     };
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        const int q = min(q0 + 16 * qt + col, T - 1);
-        qf[qt] = *reinterpret_cast<const half8_t*>(base + (int64_t)q * 3 * H + 8 * g);
+        const int q = min(q0 + 16 * qt + col, NQ - 1);
+        qf[qt] = *reinterpret_cast<const half8_t*>(qb + (int64_t)q * a.q_tok + 8 * g);
     }
     // the softmax scale (x log2 e) goes into Q once — 8 multiplies per query tile instead of one per score; the
     // product is rounded to fp16 like Q itself (|scale| < 1: no overflow), well inside the kernel's fp16 tolerance
@@ -92,8 +111,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
         const int key = piece >> 2, e = piece & 3;
         half8_t v = {0, 0, 0, 0, 0, 0, 0, 0}, kk8 = {0, 0, 0, 0, 0, 0, 0, 0};
         if (key < T) {
-            kk8 = *reinterpret_cast<const half8_t*>(base + (int64_t)key * 3 * H + H + 8 * e);
-            v = *reinterpret_cast<const half8_t*>(base + (int64_t)key * 3 * H + 2 * H + 8 * e);
+            kk8 = *reinterpret_cast<const half8_t*>(kb + (int64_t)key * a.kv_tok + 8 * e);
+            v = *reinterpret_cast<const half8_t*>(vb + (int64_t)key * a.kv_tok + 8 * e);
         }
         ks[key * 4 + (e ^ ((key >> 2) & 3))] = kk8;   // pieces of a key rotated by key / 4: the 16 lanes of a fragment read hit 16 different bank groups
         const int c = key >> 5, kk = key & 31;
@@ -105,7 +124,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
         }
     }
     __syncthreads();
-    if (q0 >= T) return;
+    if (q0 >= NQ) return;
     f32x4_t o[2][2];   // [dim tile][query tile]
     float m[2], l[2];
 #pragma unroll
@@ -198,14 +217,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
         lt += __shfl_xor(lt, 16);
         lt += __shfl_xor(lt, 32);
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
-        if (q < T) {
+        if (q < NQ) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
                 half4_t w;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][qt][r] * inv);
-                *reinterpret_cast<half4_t*>(out + ((int64_t)seq * T + q) * H + head * kAttnHeadDim + 16 * dt + 4 * g) = w;
+                *reinterpret_cast<half4_t*>(out + ((int64_t)seq * NQ + q) * H + head * kAttnHeadDim + 16 * dt + 4 * g) = w;
             }
         }
     }

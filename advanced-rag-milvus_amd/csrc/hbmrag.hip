@@ -1839,13 +1839,15 @@ int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void
     return HR_OK;
 }
 
-int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out, int64_t n_seq, int T, int heads,
-                         int head_dim, float scale, void* stream) {
-    if (n_seq < 0 || T <= 0 || heads <= 0) return fail(nullptr, HR_EINVAL, "bad attention sizes");
+static int attention_launch(const _Float16* q, int64_t q_seq, int64_t q_tok, const _Float16* k, const _Float16* v, int64_t kv_seq,
+                            int64_t kv_tok, const int32_t* d_lengths, _Float16* out, int64_t n_seq, int T, int n_queries, int heads,
+                            int head_dim, float scale, hipStream_t stream) {
+    if (n_seq < 0 || T <= 0 || heads <= 0 || n_queries <= 0 || n_queries > T) return fail(nullptr, HR_EINVAL, "bad attention sizes");
     if (head_dim != kAttnHeadDim) return fail(nullptr, HR_ELIMIT, "this attention kernel serves head dimension %d only (got %d)", kAttnHeadDim, head_dim);
     if (T > kAttnMaxT) return fail(nullptr, HR_ELIMIT, "sequence length %d exceeds %d", T, kAttnMaxT);
-    if (!d_qkv || !d_out) return fail(nullptr, HR_EINVAL, "null buffer");
-    if (((uintptr_t)d_qkv | (uintptr_t)d_out) & 15) return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
+    if (!q || !k || !v || !out) return fail(nullptr, HR_EINVAL, "null buffer");
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
+    if ((q_seq | q_tok | kv_seq | kv_tok) & 7) return fail(nullptr, HR_EINVAL, "strides must be multiples of 8 halves");
     if (n_seq == 0) return HR_OK;
     if (n_seq * heads > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many (sequence, head) pairs");
     const int n_chunks = (T + 31) / 32;
@@ -1858,22 +1860,40 @@ int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_ou
         if (e0 != hipSuccess) return fail(nullptr, HR_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e0));
         attr_set = true;
     }
-    const int NW = T <= 128 ? 4 : 8;                                   // waves (x 32 queries) per block
-    const int n_qblocks = (T + 32 * NW - 1) / (32 * NW);
-    const int64_t n_pairs = n_seq * ((heads + 1) / 2);                 // head pairs: the blocks of a pair share an XCD
-    const int64_t n_blocks = ((n_pairs + 7) / 8) * 8 * 2 * n_qblocks;
+    const int NW = n_queries <= 128 ? 4 : 8;                           // waves (x 32 queries) per block
+    AttnArgs a{};
+    a.q = q; a.k = k; a.v = v; a.out = out; a.lengths = d_lengths;
+    a.q_seq = q_seq; a.q_tok = q_tok; a.kv_seq = kv_seq; a.kv_tok = kv_tok;
+    a.T = T; a.n_queries = n_queries; a.heads = heads;
+    a.n_qblocks = (n_queries + 32 * NW - 1) / (32 * NW);
+    a.n_pairs = n_seq * ((heads + 1) / 2);                             // head pairs: the blocks of a pair share an XCD
+    a.scale_log2e = scale * 1.4426950408889634f;
+    const int64_t n_blocks = ((a.n_pairs + 7) / 8) * 8 * 2 * a.n_qblocks;
     if (n_blocks > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many attention blocks");
     if (NW == 4)
-        hipLaunchKernelGGL(attention_hd32_kernel<4>, dim3((unsigned)n_blocks), dim3(256), lds, (hipStream_t)stream,
-                           (const _Float16*)d_qkv, d_lengths, (_Float16*)d_out, T, heads, scale * 1.4426950408889634f,
-                           n_qblocks, n_pairs);
+        hipLaunchKernelGGL(attention_hd32_kernel<4>, dim3((unsigned)n_blocks), dim3(256), lds, stream, a);
     else
-        hipLaunchKernelGGL(attention_hd32_kernel<8>, dim3((unsigned)n_blocks), dim3(512), lds, (hipStream_t)stream,
-                           (const _Float16*)d_qkv, d_lengths, (_Float16*)d_out, T, heads, scale * 1.4426950408889634f,
-                           n_qblocks, n_pairs);
+        hipLaunchKernelGGL(attention_hd32_kernel<8>, dim3((unsigned)n_blocks), dim3(512), lds, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, HR_EHIP, "attention_hd32_kernel: %s", hipGetErrorString(e));
     return HR_OK;
+}
+
+int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out, int64_t n_seq, int T, int heads,
+                         int head_dim, float scale, void* stream) {
+    if (!d_qkv) return fail(nullptr, HR_EINVAL, "null buffer");
+    const int64_t H = (int64_t)heads * head_dim;
+    const _Float16* qkv = (const _Float16*)d_qkv;
+    return attention_launch(qkv, (int64_t)T * 3 * H, 3 * H, qkv + H, qkv + 2 * H, (int64_t)T * 3 * H, 3 * H, d_lengths, (_Float16*)d_out,
+                            n_seq, T, T, heads, head_dim, scale, (hipStream_t)stream);
+}
+
+int hr_attention_rows_f16_dev(const void* d_q, int64_t q_seq_stride, int64_t q_token_stride, const void* d_k, const void* d_v,
+                              int64_t kv_seq_stride, int64_t kv_token_stride, const int32_t* d_lengths, void* d_out, int64_t n_seq,
+                              int T, int n_queries, int heads, int head_dim, float scale, void* stream) {
+    return attention_launch((const _Float16*)d_q, q_seq_stride, q_token_stride, (const _Float16*)d_k, (const _Float16*)d_v, kv_seq_stride,
+                            kv_token_stride, d_lengths, (_Float16*)d_out, n_seq, T, n_queries, heads, head_dim, scale,
+                            (hipStream_t)stream);
 }
 
 // ---- host-buffer, synchronous forms -------------------------------------------------

@@ -765,11 +765,13 @@ def ce_report(ce, events, pairs: int, T: int):
     the FFN + 4 T H for the attention products) and the share of the fp16 MFMA peak."""
     cfg = ce.config
     H, L = cfg.hidden, cfg.layers
-    flops = pairs * ce.flops_per_pair(T)
+    flops = pairs * ce.flops_per_pair(T)   # the arithmetic the forward EXECUTES: last layer = keys / values + token 0 (encoders.py)
     ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else 0.0
     tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {"model": f"random-init MiniLM-L{L}-H{H} (PyTorch-ROCm, fp16)", "pairs_per_step": pairs, "seq_len": T,
-            "forward_ms_per_step": ms, "flop_per_step": flops, "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
+            "forward_ms_per_step": ms, "flop_per_step": flops,
+            "flop_per_step_if_every_layer_ran_over_every_token": pairs * ce.flops_per_pair(T, executed=False),
+            "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "forwards_timed": len(events)}
 
 

@@ -324,6 +324,14 @@ HR_API int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, con
  * T <= 1024 (K and V of a (sequence, head) are staged in LDS); HR_ELIMIT beyond. */
 HR_API int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out, int64_t n_seq, int T, int heads,
                          int head_dim, float scale, void* stream);
+/* The same kernel with its operands by pointer and stride (in halves, multiples of 8): query rows at
+ * d_q + seq * q_seq_stride + token * q_token_stride + head * 32, key / value rows at d_k / d_v + seq * kv_seq_stride +
+ * token * kv_token_stride + head * 32; the first n_queries (<= T) tokens of a sequence are its queries;
+ * d_out [n_seq][n_queries][heads * 32].  The cross-encoder's last layer, whose head reads token 0 only, calls it with
+ * n_queries = 1 over a [n_seq][T][2][heads][32] key / value buffer (advanced_rag/encoders.py). */
+HR_API int hr_attention_rows_f16_dev(const void* d_q, int64_t q_seq_stride, int64_t q_token_stride, const void* d_k, const void* d_v,
+                              int64_t kv_seq_stride, int64_t kv_token_stride, const int32_t* d_lengths, void* d_out,
+                              int64_t n_seq, int T, int n_queries, int heads, int head_dim, float scale, void* stream);
 
 /* ---- streams with a compute-unit mask -------------------------------------------
  * A HIP stream whose kernels may only occupy the compute units named by `cu_mask` (bit i of word i/32 = CU i;

@@ -40,7 +40,7 @@ def run(name, ce, tunable=False, profile=False):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / 10
         tf = P * ce.flops_per_pair(T) / (ms * 1e-3) / 1e12
-        print(f"{name:34s} {ms:8.3f} ms/forward  {tf:7.1f} TFLOP/s = {tf / 2500:.3f} of the fp16 MFMA peak (warm-up {warm:.1f}s)", flush=True)
+        print(f"{name:34s} {ms:8.3f} ms/forward  {tf:7.1f} TFLOP/s executed = {tf / 2500:.3f} of the fp16 MFMA peak (warm-up {warm:.1f}s)", flush=True)
         if profile:
             from torch.profiler import ProfilerActivity, profile as prof
             with prof(activities=[ProfilerActivity.CUDA]) as p:

@@ -54,6 +54,42 @@ def test_cross_encoder_cpu_predict_and_local_weights(tmp_path):
     assert torch.allclose(ce.module.state_dict()["head.weight"], torch.full_like(sd["head.weight"], 0.5))
 
 
+def test_cross_encoder_last_layer_for_token_0_only_gives_the_same_logits():
+    """The relevance head reads token 0: the last layer computes keys / values for every token and everything else for
+    token 0 alone (encoders._Layer.forward_first_token).  Same logits as the layer run over every token — fp32 on the
+    CPU here (ragged lengths), fp16 on the GPU below."""
+    ce = CrossEncoderModel(EncoderConfig(vocab_size=2000, hidden=64, layers=3, heads=2, intermediate=128, max_len=64),
+                           device="cpu", max_len=64)
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(1, 2000, (9, 37), generator=g)
+    ids[2, 12:] = 0
+    ids[5, 1:] = 0
+    types = (torch.arange(37)[None, :] >= 9).long().expand(9, -1).contiguous()
+    mask = ids != 0
+    with torch.inference_mode():
+        a = ce.module(ids, types, mask)
+        b = ce.module(ids, types, mask, all_tokens_last_layer=True)
+    assert a.shape == (9,) and torch.allclose(a, b, atol=1e-6, rtol=1e-5)
+    full, run = ce.flops_per_pair(128, executed=False), ce.flops_per_pair(128)
+    assert 0.5 < run / full < 1.0
+
+
+@pytest.mark.gpu
+def test_cross_encoder_last_layer_for_token_0_only_on_the_gpu(gpu):
+    ce = CrossEncoderModel(EncoderConfig(gelu="tanh"), device="cuda:0", max_len=512)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    ids = torch.randint(1000, 30000, (64, 128), device="cuda", generator=g)
+    ids[:, 0] = 101
+    ids[3, 70:] = 0
+    ids[9, 5:] = 0
+    types = (torch.arange(128, device="cuda")[None, :] >= 32).long().expand(64, -1).contiguous()
+    mask = ids != 0
+    with torch.inference_mode():
+        a = ce.module(ids, types, mask)
+        b = ce.module(ids, types, mask, all_tokens_last_layer=True)
+    assert torch.isfinite(a).all() and torch.allclose(a, b, atol=2e-3, rtol=2e-2), (a - b).abs().max()
+
+
 @pytest.mark.gpu
 def test_encoders_drive_the_pipeline_on_gpu(gpu):
     from advanced_rag import AdvancedRAGPipeline, BM25SparseEncoder, CrossEncoderReranker, PipelineConfig
@@ -248,5 +284,16 @@ def test_attention_hd32_kernel_matches_sdpa_fp32(gpu, n_seq, T, heads, grow):
     assert torch.allclose(out.float(), want, atol=atol, rtol=rtol)
     with pytest.raises(nat.HbmRagError):
         nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), n_seq, T, heads, 64, 0.125, 0)
+    # operands by pointer and stride: the first nq tokens as queries over a separate [n_seq, T, 2, heads, 32] K / V buffer
+    kvbuf = qkv[:, :, 1:].contiguous()
+    for nq in sorted({1, min(T, 33), min(T, 160)}):
+        qrows = qkv[:, :nq, 0].contiguous()                                   # [n_seq, nq, heads, 32]
+        o2 = torch.full((n_seq, nq, H), float("nan"), dtype=torch.float16, device="cuda")
+        nat.attention_rows_f16_dev(qrows.data_ptr(), nq * H, H, kvbuf.data_ptr(), kvbuf.data_ptr() + 2 * H, T * 2 * H, 2 * H,
+                                   lengths.data_ptr(), o2.data_ptr(), n_seq, T, nq, heads, 32, 32 ** -0.5,
+                                   torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        w2 = torch.nn.functional.scaled_dot_product_attention(q[:, :, :nq], k, v, attn_mask=bias).transpose(1, 2).reshape(n_seq, nq, H)
+        assert torch.allclose(o2.float(), w2, atol=atol, rtol=rtol), (nq, (o2.float() - w2).abs().max())
     with pytest.raises(nat.HbmRagError):   # K and V of a (sequence, head) must fit LDS
         nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), 1, 1025, heads, 32, 0.125, 0)
