@@ -101,6 +101,9 @@ _SIGNATURES = {
                                         _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "hr_add_layernorm_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64,
                                             _c.c_int, _c.c_float, _c.c_void_p]),
+    "hr_embed_layernorm_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                              _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_float, _c.c_int64,
+                                              _c.c_int64, _c.c_void_p]),
     "hr_attention_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
                                         _c.c_float, _c.c_void_p]),
     "hr_attention_rows_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
@@ -502,6 +505,17 @@ def add_layernorm_f16_dev(d_x: int, d_residual: int, d_gamma: int, d_beta: int, 
     L = load_library()
     rc = L.hr_add_layernorm_f16_dev(_vp(d_x), _vp(d_residual) if d_residual else None, _vp(d_gamma), _vp(d_beta),
                                     _vp(d_out), rows, hidden, eps, _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def embed_layernorm_f16_dev(d_ids: int, d_types: int, d_word: int, d_pos: int, d_seg: int, d_gamma: int, d_beta: int, d_out: int,
+                            n_seq: int, T: int, hidden: int, eps: float, n_word: int, n_seg: int, stream: int = 0):
+    """out[s, t] = LayerNorm(word[ids[s, t]] + pos[t] + seg[types[s, t]]): int64 ids / types (clamped into the tables),
+    fp16 tables and output."""
+    L = load_library()
+    rc = L.hr_embed_layernorm_f16_dev(_vp(d_ids), _vp(d_types), _vp(d_word), _vp(d_pos), _vp(d_seg), _vp(d_gamma), _vp(d_beta),
+                                      _vp(d_out), n_seq, T, hidden, float(eps), n_word, n_seg, _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
 

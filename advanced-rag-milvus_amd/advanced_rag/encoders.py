@@ -183,8 +183,20 @@ class BertEncoder(nn.Module):
     def forward(self, ids, types, mask, first_token_only: bool = False):
         """-> hidden states [B, T, H]; with first_token_only, [B, 1, H]: the last layer computes token 0 alone
         (_Layer.forward_first_token) — for heads that read nothing else."""
-        T = ids.shape[1]
-        x = add_layer_norm(self.word(ids) + self.pos(torch.arange(T, device=ids.device))[None], self.seg(types), self.ln)
+        B, T = ids.shape
+        if ids.is_cuda and self.word.weight.dtype == torch.float16 and T <= self.pos.weight.shape[0]:
+            # the embedding layer in one HIP kernel: two gathers, the position rows, both adds and the LayerNorm (ids outside
+            # the tables are clamped by the kernel: no check here that would synchronise the stream)
+            ids_c, types_c = ids.contiguous().long(), types.contiguous().long()
+            H = self.word.weight.shape[1]
+            x = torch.empty((B, T, H), dtype=torch.float16, device=ids.device)
+            _native.embed_layernorm_f16_dev(ids_c.data_ptr(), types_c.data_ptr(), self.word.weight.data_ptr(),
+                                            self.pos.weight.data_ptr(), self.seg.weight.data_ptr(), self.ln.weight.data_ptr(),
+                                            self.ln.bias.data_ptr(), x.data_ptr(), B, T, H, float(self.ln.eps),
+                                            self.word.weight.shape[0], self.seg.weight.shape[0],
+                                            torch.cuda.current_stream(ids.device).cuda_stream)
+        else:
+            x = add_layer_norm(self.word(ids) + self.pos(torch.arange(T, device=ids.device))[None], self.seg(types), self.ln)
         bias = torch.zeros(mask.shape, dtype=x.dtype, device=x.device).masked_fill(~mask, float("-inf"))[:, None, None, :]
         # valid tokens per sequence for the HIP attention kernel: padding sits at the tail (HashTokenizer.batch), so the
         # key mask is "position < length"

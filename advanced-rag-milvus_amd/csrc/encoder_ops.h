@@ -77,4 +77,65 @@ __global__ __launch_bounds__(256) void add_layernorm_f16_kernel(const half8_t* _
     }
 }
 
+// The embedding layer of the same models in one pass: out[s, t] = LayerNorm(word[ids[s, t]] + pos[t] + seg[types[s, t]]).
+// PyTorch runs two gathers, a broadcast add and the add + LayerNorm above — ~1.8 GB of traffic at 2560 x 128 tokens x 384
+// dims for 0.25 GB of output; here the three table rows come from L2 and only the output goes to HBM.  The two adds are
+// rounded to fp16 one after the other, as the unfused fp16 module rounds them.  Ids / types outside the tables are clamped
+// to the tables' first / last row (no read out of bounds, no host-side check that would synchronise the stream).
+template <int NC>
+__global__ __launch_bounds__(256) void embed_layernorm_f16_kernel(const int64_t* __restrict__ ids, const int64_t* __restrict__ types,
+                                                                  const half8_t* __restrict__ word, const half8_t* __restrict__ pos,
+                                                                  const half8_t* __restrict__ seg, const half8_t* __restrict__ gamma,
+                                                                  const half8_t* __restrict__ beta, half8_t* __restrict__ out,
+                                                                  int64_t rows, int T, int chunks, float eps, int64_t n_word, int64_t n_seg) {
+    const int j = threadIdx.x & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (row >= rows) return;  // a whole DPP row leaves together
+    const half8_t* wr = word + min(max(ids[row], (int64_t)0), n_word - 1) * chunks;
+    const half8_t* pr = pos + (row % T) * chunks;
+    const half8_t* sr = seg + min(max(types[row], (int64_t)0), n_seg - 1) * chunks;
+    half8_t h[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = j + 16 * i;
+        if (c < chunks) {
+            h[i] = wr[c] + pr[c];     // fp16 adds, each rounded to nearest
+            h[i] = h[i] + sr[c];
+        } else {
+            h[i] = (half8_t)(_Float16)0;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)h[i][e];
+    const float inv_n = 1.0f / (float)(chunks * 8);
+    const float mean = row16_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        if (j + 16 * i < chunks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = (float)h[i][e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(row16_sum(q) * inv_n + eps);
+    half8_t* orow = out + row * chunks;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = j + 16 * i;
+        if (c < chunks) {
+            const half8_t g = gamma[c], b = beta[c];
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)(((float)h[i][e] - mean) * rstd * (float)g[e] + (float)b[e]);
+            orow[c] = o;
+        }
+    }
+}
+
 }  // namespace hbmrag

@@ -1839,6 +1839,36 @@ int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void
     return HR_OK;
 }
 
+int hr_embed_layernorm_f16_dev(const int64_t* d_ids, const int64_t* d_types, const void* d_word, const void* d_pos, const void* d_seg,
+                               const void* d_gamma, const void* d_beta, void* d_out, int64_t n_seq, int T, int hidden, float eps,
+                               int64_t n_word, int64_t n_seg, void* stream) {
+    if (n_word <= 0 || n_seg <= 0) return fail(nullptr, HR_EINVAL, "empty embedding table");
+    if (n_seq < 0 || T <= 0 || hidden <= 0 || hidden % 8 != 0) return fail(nullptr, HR_EINVAL, "hidden must be a positive multiple of 8");
+    if (hidden > 1024) return fail(nullptr, HR_ELIMIT, "hidden exceeds 1024");
+    if (!d_ids || !d_types || !d_word || !d_pos || !d_seg || !d_gamma || !d_beta || !d_out) return fail(nullptr, HR_EINVAL, "null buffer");
+    if (((uintptr_t)d_word | (uintptr_t)d_pos | (uintptr_t)d_seg | (uintptr_t)d_gamma | (uintptr_t)d_beta | (uintptr_t)d_out) & 15)
+        return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
+    const int64_t rows = n_seq * T;
+    if (rows == 0) return HR_OK;
+    const int chunks = hidden / 8;
+    const dim3 grid((unsigned)((rows + 15) / 16)), block(256);
+    auto* w = (const half8_t*)d_word;
+    auto* p = (const half8_t*)d_pos;
+    auto* sg = (const half8_t*)d_seg;
+    auto* g = (const half8_t*)d_gamma;
+    auto* b = (const half8_t*)d_beta;
+    auto* o = (half8_t*)d_out;
+    hipStream_t s = (hipStream_t)stream;
+    if (chunks <= 16) hipLaunchKernelGGL((embed_layernorm_f16_kernel<1>), grid, block, 0, s, d_ids, d_types, w, p, sg, g, b, o, rows, T, chunks, eps, n_word, n_seg);
+    else if (chunks <= 32) hipLaunchKernelGGL((embed_layernorm_f16_kernel<2>), grid, block, 0, s, d_ids, d_types, w, p, sg, g, b, o, rows, T, chunks, eps, n_word, n_seg);
+    else if (chunks <= 48) hipLaunchKernelGGL((embed_layernorm_f16_kernel<3>), grid, block, 0, s, d_ids, d_types, w, p, sg, g, b, o, rows, T, chunks, eps, n_word, n_seg);
+    else if (chunks <= 64) hipLaunchKernelGGL((embed_layernorm_f16_kernel<4>), grid, block, 0, s, d_ids, d_types, w, p, sg, g, b, o, rows, T, chunks, eps, n_word, n_seg);
+    else hipLaunchKernelGGL((embed_layernorm_f16_kernel<8>), grid, block, 0, s, d_ids, d_types, w, p, sg, g, b, o, rows, T, chunks, eps, n_word, n_seg);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "embed_layernorm_f16_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
 static int attention_launch(const _Float16* q, int64_t q_seq, int64_t q_tok, const _Float16* k, const _Float16* v, int64_t kv_seq,
                             int64_t kv_tok, const int32_t* d_lengths, _Float16* out, int64_t n_seq, int T, int n_queries, int heads,
                             int head_dim, float scale, hipStream_t stream) {

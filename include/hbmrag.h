@@ -317,6 +317,13 @@ HR_API int hr_filter_eval_dev(const hr_filter_term* terms, int n_terms, int64_t 
 HR_API int hr_add_layernorm_f16_dev(const void* d_x, const void* d_residual, const void* d_gamma, const void* d_beta,
                              void* d_out, int64_t rows, int hidden, float eps, void* stream);
 
+/* The embedding layer of the same models in one pass: d_out[s][t] = LayerNorm(word[ids[s][t]] + pos[t] + seg[types[s][t]])
+ * (fp16 tables and output, hidden as above; ids / types int64, clamped into [0, n_word) / [0, n_seg); d_pos holds at least
+ * T rows; the two adds are rounded to fp16 one after the other, as the unfused fp16 module rounds them). */
+HR_API int hr_embed_layernorm_f16_dev(const int64_t* d_ids, const int64_t* d_types, const void* d_word, const void* d_pos,
+                               const void* d_seg, const void* d_gamma, const void* d_beta, void* d_out, int64_t n_seq, int T,
+                               int hidden, float eps, int64_t n_word, int64_t n_seg, void* stream);
+
 /* Self-attention for head dimension 32, from the fused QKV projection's output to the layout the output projection
  * reads (the PyTorch SDPA call plus the permute / transpose copies around it, in one kernel):
  *   d_qkv [n_seq][T][3][heads][32] fp16, d_lengths[n_seq] valid tokens per sequence (padding at the tail; NULL = T),

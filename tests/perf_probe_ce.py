@@ -24,7 +24,8 @@ mask = torch.ones((P, T), dtype=torch.bool, device=dev)
 def run(name, ce, tunable=False, profile=False):
     if tunable:
         torch.cuda.tunable.enable(True)
-        torch.cuda.tunable.set_max_tuning_duration(200)
+        torch.cuda.tunable.set_max_tuning_duration(int(os.environ.get("PROBE_TUNE_MS", "200")))
+        torch.cuda.tunable.set_max_tuning_iterations(int(os.environ.get("PROBE_TUNE_ITERS", "100")))
         torch.cuda.tunable.set_filename(os.path.join(ROOT, "gpurun_out", "tunableop_ce.csv"))
     with torch.inference_mode():
         t0 = time.time()
@@ -52,6 +53,9 @@ def run(name, ce, tunable=False, profile=False):
         torch.cuda.tunable.enable(False)
 
 
+if os.environ.get("PROBE_NO_RECORDED") == "1":   # tune every shape from scratch: the shipped solutions are not loaded
+    import advanced_rag.encoders as _enc
+    _enc._TUNED_GEMMS = False
 ce = CrossEncoderModel(EncoderConfig(gelu="tanh"), device=str(dev), max_len=512)
 print("recorded hipBLASLt solutions in use:", ce.tuned_gemms, flush=True)
 run("tanh gelu epilogue + HIP attention + recorded GEMM solutions", ce, profile=True)

@@ -206,6 +206,40 @@ def test_fused_add_layernorm_matches_torch_fp32(gpu, rows, hidden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_seq,T,hidden", [(3, 7, 64), (40, 128, 384), (5, 33, 768), (2, 512, 1024)])
+def test_fused_embedding_layernorm_matches_the_unfused_fp16_ops(gpu, n_seq, T, hidden):
+    """hr_embed_layernorm_f16_dev against the ops it replaces, run the way the unfused fp16 module runs them (gather, fp16
+    add of the position rows, fp16 add of the segment rows, LayerNorm with fp32 statistics): the same roundings, so only
+    the last LayerNorm's arithmetic differs — within one fp16 ulp of the output; ids outside the tables are clamped."""
+    from advanced_rag import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(hidden + T)
+    V = 1000
+    word = (torch.randn((V, hidden), device="cuda", generator=g) * 0.5).half()
+    pos = (torch.randn((512, hidden), device="cuda", generator=g) * 0.5).half()
+    seg = (torch.randn((2, hidden), device="cuda", generator=g) * 0.5).half()
+    gamma = (1 + 0.1 * torch.randn(hidden, device="cuda", generator=g)).half()
+    beta = (0.1 * torch.randn(hidden, device="cuda", generator=g)).half()
+    ids = torch.randint(0, V, (n_seq, T), device="cuda", generator=g)
+    types = torch.randint(0, 2, (n_seq, T), device="cuda", generator=g)
+    out = torch.empty((n_seq, T, hidden), dtype=torch.float16, device="cuda")
+
+    def run(i, t):
+        nat.embed_layernorm_f16_dev(i.data_ptr(), t.data_ptr(), word.data_ptr(), pos.data_ptr(), seg.data_ptr(), gamma.data_ptr(),
+                                    beta.data_ptr(), out.data_ptr(), n_seq, T, hidden, 1e-12, V, 2, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return out.clone()
+
+    got = run(ids, types)
+    h = (word[ids] + pos[:T][None]) + seg[types]                      # fp16, rounded after each add
+    want = torch.nn.functional.layer_norm(h.float(), (hidden,), gamma.float(), beta.float(), 1e-12)
+    assert torch.allclose(got.float(), want, atol=2e-3, rtol=2e-3), (got.float() - want).abs().max()
+    wild_i, wild_t = ids.clone(), types.clone()
+    wild_i[0, 0], wild_i[-1, -1], wild_t[0, 0] = -5, V + 9, 7
+    ref_i, ref_t = wild_i.clamp(0, V - 1), wild_t.clamp(0, 1)
+    assert torch.equal(run(wild_i, wild_t), run(ref_i, ref_t))
+
+
+@pytest.mark.gpu
 def test_encoder_forward_with_the_fused_layernorm_matches_the_unfused_module(gpu):
     """The fp16 GPU forward (fused add + LayerNorm) against the same module run unfused in fp32 on the same weights."""
     from advanced_rag.encoders import BertEncoder
