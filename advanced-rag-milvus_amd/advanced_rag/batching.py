@@ -309,7 +309,10 @@ class SearchCoalescer:
         self.stats["hybrid_launches"] += 1
         self.stats["dense_launches"] += 1
         self.stats["sparse_launches"] += 1
-        return {"b": b, "keep": (q, d_sparse, mask)}
+        # the engine reuses ONE buffer set per batch size: another group (or the next chunk of this one) with the same B
+        # is enqueued before this round is read back, so the results are copied out here, in stream order
+        out = {k: b[k].clone() for k in ("fused_ids", "fused_scores", "fused_methods", "fused_n", "ids", "scores", "flags")}
+        return {"b": out, "keep": (q, d_sparse, mask)}
 
     def _scatter_hybrid(self, key, chunk, st):
         b = st["b"]

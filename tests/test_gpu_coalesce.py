@@ -132,8 +132,20 @@ def test_128_concurrent_retrieves_equal_sequential_calls(gpu, long_timeout):
                 assert st["dense_launches"] + st["sparse_launches"] <= (2 * (nq + nq // 4)) // 4, st   # >= 4 queries per launch
                 assert st["max_batch_seen"] >= 16, st
                 assert (st["hybrid_launches"] > 0) == one_round and (st["fuse_launches"] == 0 or not one_round or st["redone_unproven"] > 0)
+                if one_round:
+                    # groups of EQUAL size in one round (8 plain + 8 filtered requests) and two chunks of one group (136 + 8
+                    # plain requests: chunks of 128 and 16): the engine's per-batch-size buffers must not be shared between
+                    # launches that are read back together
+                    async def same_size():
+                        plain = [retr.retrieve(f"q{i}", profile_hint="default") for i in list(range(8)) + list(range(nq))]
+                        filt = [retr.retrieve(f"q{i}", filters={"chunk_index": {"$lt": 5}}, profile_hint="default") for i in range(0, 32, 4)]
+                        return await asyncio.gather(*plain, *filt)
+                    o2 = asyncio.run(same_size())
+                    results["same_size_groups"] = ([_strip(o) for o in o2[:8 + nq]], [_strip(o) for o in o2[8 + nq:]])
                 seq2 = asyncio.run(sequential())          # the front also serves one caller at a time
-                assert [_strip(o) for o in seq2] == results[tag]
+                got2 = [_strip(o) for o in seq2]
+                bad = [(i, j, a, b) for i, (x, y) in enumerate(zip(got2, results[tag])) for j, (a, b) in enumerate(zip(x, y)) if a != b]
+                assert not bad and got2 == results[tag], (len(bad), bad[:2])
             else:
                 results["sequential"] = [_strip(o) for o in asyncio.run(sequential())]
 
@@ -147,8 +159,12 @@ def test_128_concurrent_retrieves_equal_sequential_calls(gpu, long_timeout):
     wide = results["wide"]
     assert all(len(r) == 100 for r in wide[(False, False)])
     assert wide[(True, False)] == wide[(False, False)] and wide[(True, True)] == wide[(False, False)]
+    bad = [(i, j, a, b) for i, (x, y) in enumerate(zip(results["concurrent"], results["sequential"])) for j, (a, b) in enumerate(zip(x, y)) if a != b]
+    assert not bad, (len(bad), bad[:2])
     assert results["concurrent"] == results["sequential"]
     assert results["concurrent_filtered"] == results["filtered_sequential"]
+    assert results["same_size_groups"][0] == results["sequential"][:8] + results["sequential"]
+    assert results["same_size_groups"][1] == results["filtered_sequential"][:8]
     assert results["one_round"] == results["sequential"]
     assert results["one_round_filtered"] == results["filtered_sequential"]
     assert all(r[3] < 5 for lst in results["one_round_filtered"] for r in lst)
