@@ -27,10 +27,7 @@ namespace hbmrag {
 constexpr int kAttnHeadDim = 32;
 constexpr int kAttnMaxT = 1024;   // K + V of a (sequence, head) in LDS: 128 bytes per token
 
-__device__ inline float wave_col_max(float v) {   // over the four lane groups that share a query column
-    v = fmaxf(v, __shfl_xor(v, 16));
-    return fmaxf(v, __shfl_xor(v, 32));
-}
+__device__ inline float wave_col_max(float v) { return col4_max(v); }   // over the four lane groups that share a query column
 
 // Operands by pointer and stride (AttnArgs): the fused QKV buffer [n_seq][T][3][heads][32] of an encoder layer, or separate
 // query rows and a KV buffer (the cross-encoder's last layer: ONE query row per sequence against [n_seq][T][2][heads][32]).
@@ -214,8 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + 16 * qt + col;
         float lt = l[qt];
-        lt += __shfl_xor(lt, 16);
-        lt += __shfl_xor(lt, 32);
+        lt = col4_sum(lt);
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
         if (q < NQ) {
 #pragma unroll

@@ -68,6 +68,36 @@ __device__ inline unsigned wave_scan_add(unsigned x) {
 }
 __device__ inline unsigned wave_sum(unsigned x) { return (unsigned)__builtin_amdgcn_readlane((int)wave_scan_add(x), 63); }
 
+// Maximum / sum over the four lanes l, l ^ 16, l ^ 32, l ^ 48 (the lanes that hold one COLUMN of a 16-wide MFMA tile),
+// result in all four: two gfx950 row swaps (v_permlane32_swap / v_permlane16_swap: VALU, no LDS round trip) instead of two
+// ds_bpermute — the scans' epilogues run this once per (row block, query group) with their loads waiting behind it.
+// The swaps are issued as inline asm: through the builtins hipcc folded max(result[0], result[1]) into result[0] (ROCm
+// 7.2: it does not model that the swap makes the two results differ when both operands hold the same value) — the column
+// maxima were then maxima over one lane.  s_nop on both sides: the hazard recogniser does not see into the asm
+// (VALU write -> permlane swap read, permlane swap write -> VALU read).
+__device__ inline void permlane32_swap(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ inline void permlane16_swap(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ inline float col4_max(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    permlane32_swap(a, b);   // a = [lo, lo], b = [hi, hi]
+    v = fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+    a = b = __builtin_bit_cast(unsigned, v);
+    permlane16_swap(a, b);   // a = [r0, r0, r2, r2], b = [r1, r1, r3, r3]
+    return fmaxf(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b));
+}
+__device__ inline float col4_sum(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    permlane32_swap(a, b);
+    v = __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+    a = b = __builtin_bit_cast(unsigned, v);
+    permlane16_swap(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
 __device__ inline float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));

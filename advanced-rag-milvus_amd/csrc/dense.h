@@ -232,8 +232,7 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
                         mr = fmaxf(mr, v);
                     }
                     if (NRB == 1) {  // this row block is a candidate group of its own
-                        mr = fmaxf(mr, __shfl_xor(mr, 16));
-                        mr = fmaxf(mr, __shfl_xor(mr, 32));
+                        mr = col4_max(mr);
                         if (lane < 16 && 16 * g + lane < nq)
                             gmax[(int64_t)(16 * g + lane) * gmax_stride + group * kRowBlocksPerSuper + pair * RS + s] = mr;
                     } else {
@@ -246,8 +245,7 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 float v = m[g];
-                v = fmaxf(v, __shfl_xor(v, 16));
-                v = fmaxf(v, __shfl_xor(v, 32));
+                v = col4_max(v);
                 if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * gmax_stride + group] = v;
             }
         }
@@ -396,8 +394,7 @@ __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
                             mr = fmaxf(mr, v);
                         }
                         if (NRB == 1) {
-                            mr = fmaxf(mr, __shfl_xor(mr, 16));
-                            mr = fmaxf(mr, __shfl_xor(mr, 32));
+                            mr = col4_max(mr);
                             if (lane < 16 && 16 * g + lane < nq)
                                 gmax[(int64_t)(16 * g + lane) * gmax_stride + group * kRowBlocksPerSuper + pair * RS + s] = mr;
                         } else {
@@ -411,8 +408,7 @@ __global__ __launch_bounds__(512) void dense_scan_bigq_kernel(
 #pragma unroll
             for (int g = 0; g < GQ; ++g) {
                 float v = m[g];
-                v = fmaxf(v, __shfl_xor(v, 16));
-                v = fmaxf(v, __shfl_xor(v, 32));
+                v = col4_max(v);
                 if (lane < 16 && 16 * g + lane < nq) gmax[(int64_t)(16 * g + lane) * gmax_stride + group] = v;
             }
         }
@@ -587,8 +583,7 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
                     mr = fmaxf(mr, v);
                 }
                 if (NRB == 1) {
-                    mr = fmaxf(mr, __shfl_xor(mr, 16));
-                    mr = fmaxf(mr, __shfl_xor(mr, 32));
+                    mr = col4_max(mr);
                     if (lane < 16 && q < nq) gmax[(int64_t)q * gmax_stride + sg * kRowBlocksPerSuper + rbi] = mr;
                 } else {
                     m[gq] = fmaxf(m[gq], mr);
@@ -600,8 +595,7 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
             for (int gq = 0; gq < GW; ++gq) {
                 const int q = 16 * (wid * GW + gq) + (lane & 15);
                 float v = m[gq];
-                v = fmaxf(v, __shfl_xor(v, 16));
-                v = fmaxf(v, __shfl_xor(v, 32));
+                v = col4_max(v);
                 if (lane < 16 && q < nq) gmax[(int64_t)q * gmax_stride + sg] = v;
             }
         }
@@ -831,8 +825,7 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
                 }
                 float mr = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
                 if (NRB == 1) {
-                    mr = fmaxf(mr, __shfl_xor(mr, 16));
-                    mr = fmaxf(mr, __shfl_xor(mr, 32));
+                    mr = col4_max(mr);
                     const int q = 16 * (wq * WB + g) + (lane & 15);
                     if (lane < 16 && q < nq && rb0 + r < n_rb) gmax[(int64_t)q * gmax_stride + rb0 + r] = mr;
                 } else {
@@ -847,8 +840,7 @@ __global__ __launch_bounds__(512) void dense_scan_gemm_kernel(
 #pragma unroll
                 for (int g = 0; g < WB; ++g) {
                     float v = m[h2][g];
-                    v = fmaxf(v, __shfl_xor(v, 16));
-                    v = fmaxf(v, __shfl_xor(v, 32));
+                    v = col4_max(v);
                     const int q = 16 * (wq * WB + g) + (lane & 15);
                     if (lane < 16 && q < nq && sg < n_super) gmax[(int64_t)q * gmax_stride + sg] = v;
                 }
