@@ -732,10 +732,10 @@ class MilvusIndexManager:
         w = list(weights) + [0.0] * (2 - len(weights))
         fut = front.submit("hybrid", (int(top_k), filters, drop, float(w[0]), float(w[1]), int(rrf_k)), (dense_embedding, payload))
         try:
-            res = await asyncio.wait_for(asyncio.wrap_future(fut), timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)
-        except asyncio.TimeoutError:
-            logging.error("shard search timeout for the hybrid request")
-            return []          # both searches of the request timed out: the general path would fuse two empty lists
+            # no timer of its own: the caller (HybridRetriever.retrieve) already bounds the whole request with
+            # RetrievalConstants.TIMEOUT_SECONDS, and a wait_for here is a task + a timer handle per request on the event
+            # loop that serves every in-flight retrieve()
+            res = await asyncio.wrap_future(fut)
         except Exception:
             return None
         if res is None:
