@@ -286,6 +286,7 @@ class CollectiveShardSet:
         self._mask_ids = {}         # rank 0: id(filter array) -> (mask id, the array: keeps the id alive)
         self._next_mask_id = 1
         self.n_collectives = 0      # broadcasts + gathers issued (tests count them)
+        self._side = None           # one worker thread: the dense search of a round that also carries sparse queries
 
     # shape, as ShardSet
     n_shards = property(lambda self: self.world)
@@ -389,11 +390,18 @@ class CollectiveShardSet:
         drop = float(np.array([hdr[6]], dtype=np.int64).view(np.float64)[0])
         off = self.HEADER * 8
         out = []
+        dense_job = None
         if Bd:
             q = pkt[off: off + Bd * dim * 4].view(np.float32).reshape(Bd, dim)
             off += Bd * dim * 4
             kd = None if keep_local is None else keep_local[: self.local.num_rows]
-            out.append(self.local.search_dense(q, k, kd))
+            if Bs:   # both modalities in the round: the dense search runs beside the sparse one (ctypes releases the GIL)
+                if self._side is None:
+                    self._side = ThreadPoolExecutor(max_workers=1, thread_name_prefix="round-dense-")
+                dense_job = self._side.submit(self.local.search_dense, q, k, kd)
+                out.append(None)
+            else:
+                out.append(self.local.search_dense(q, k, kd))
         if Bs:
             ptr = pkt[off: off + (Bs + 1) * 8].view(np.int64)
             off += (Bs + 1) * 8
@@ -402,7 +410,15 @@ class CollectiveShardSet:
             val = pkt[off: off + nnz * 4].view(np.float32)
             queries = [(idx[ptr[b]:ptr[b + 1]], val[ptr[b]:ptr[b + 1]]) for b in range(Bs)]
             ks = None if keep_local is None else keep_local[: self.local.num_sparse_rows]
-            out.append(self.local.search_sparse(queries, k, drop, ks))
+            try:
+                out.append(self.local.search_sparse(queries, k, drop, ks))
+            finally:
+                if dense_job is not None:   # never leave the side thread running into the next round
+                    dense_err = dense_job.exception()
+            if dense_job is not None:
+                if dense_err is not None:
+                    raise dense_err
+                out[0] = dense_job.result()
         return out
 
     def _round(self, body, mask_bytes):
@@ -473,9 +489,16 @@ class CollectiveShardSet:
             hdr = np.zeros(self.HEADER, dtype=np.int64)
             hdr[0] = self.OP_STOP
             self._send_packet(hdr.view(np.uint8))
+        self._close_side()
+
+    def _close_side(self):
+        if self._side is not None:
+            self._side.shutdown(wait=False)
+            self._side = None
 
     # ------------------------------------------------------------------ ranks > 0
     def serve(self):
         """Answer rank 0's rounds until it sends OP_STOP."""
         while self._round(None, None):
             pass
+        self._close_side()
