@@ -139,12 +139,14 @@ struct hr_index {
     std::vector<int32_t> pend_idx;
     std::vector<float> pend_val;
     std::vector<int64_t> h_range_base{0};  // first posting of every range's block (+ total), host copy
+    std::vector<unsigned> h_range_dense;   // dense runs per range (sparse.h)
     // n_sparse rows added; n_csr / nnz_csr of them in the device CSR; n_sparse_built of them in the postings
     int64_t n_sparse = 0, n_csr = 0, nnz_csr = 0, n_sparse_built = 0;
     float max_sparse_abs = 0.f;  // max |doc weight|: bounds the scan's fixed-point range
     DevBuf s_indptr, s_idx, s_val, rt_off, range_base, post;  // post: packed (fp16 weight | u16 accumulator slot)
     DevBuf idle_post;  // 64 x 4 idle postings: what scan lanes with nothing to fetch read (sparse.h)
     int64_t n_ranges = 0;
+    int64_t n_dense_runs = 0;      // (term, range) runs in the dense form (sparse.h): the scan's variant is chosen by it
 
     bool finalized = false;
     int profiling = 0;
@@ -794,11 +796,18 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
         Span sp(h, s, PH_SSCAN);
         const int rpb = sparse_ranges_per_block(h, B);
         const unsigned chunks = (unsigned)((h->n_ranges + rpb - 1) / rpb);
-        hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)B, chunks), dim3(kScanThreads), 0, s,
-                           h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
-                           ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
-                           ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, rpb,
-                           h->idle_post.as<uint32_t>(), ws->gmax.as<float>());
+        if (h->n_dense_runs > 0)
+            hipLaunchKernelGGL(sparse_scan_kernel<true>, dim3((unsigned)B, chunks), dim3(kScanThreads), 0, s,
+                               h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
+                               ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
+                               ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, rpb,
+                               h->idle_post.as<uint32_t>(), ws->gmax.as<float>());
+        else
+            hipLaunchKernelGGL(sparse_scan_kernel<false>, dim3((unsigned)B, chunks), dim3(kScanThreads), 0, s,
+                               h->rt_off.as<unsigned int>(), V1, h->range_base.as<int64_t>(), h->post.as<uint32_t>(),
+                               ws->pq_n.as<int32_t>(), ws->pq_idx.as<int32_t>(), ws->pq_w.as<float>(), stride,
+                               ws->qscale.as<float>(), d_mask, h->n_sparse, n_groups, GR, h->n_ranges, rpb,
+                               h->idle_post.as<uint32_t>(), ws->gmax.as<float>());
         HIP_TRY(h, hipGetLastError());
     }
     if (!(phases & PHASE_FINISH)) return HR_OK;
@@ -1074,7 +1083,11 @@ int build_sparse(hr_index* h) {
     HIP_TRY(h, hipMemcpyAsync(ht.data(), tmp.totals.p, (size_t)dirty * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     h->h_range_base.resize(n_ranges + 1);
-    for (int64_t r = r_d; r < n_ranges; ++r) h->h_range_base[r + 1] = h->h_range_base[r] + (int64_t)ht[r - r_d];
+    h->h_range_dense.resize(n_ranges);
+    for (int64_t r = r_d; r < n_ranges; ++r) {
+        h->h_range_base[r + 1] = h->h_range_base[r] + (int64_t)(ht[r - r_d] & 0xFFFFFFFFull);
+        h->h_range_dense[r] = (unsigned)(ht[r - r_d] >> 32);
+    }
     // runs are padded to 4 postings (filler postings); + slack: the scan fetches 16 bytes at a time
     HIP_TRY(h, h->post.grow((size_t)h->h_range_base[n_ranges] * 4 + 64, (size_t)h->h_range_base[r_d] * 4, s));
     HIP_TRY(h, h->range_base.grow((size_t)(n_ranges + 1) * 8, 0, s));
@@ -1082,10 +1095,17 @@ int build_sparse(hr_index* h) {
     HIP_TRY(h, tmp.cursor.ensure((size_t)dirty * V1 * 4));
     HIP_TRY(h, hipMemcpyAsync(tmp.cursor.p, h->rt_off.as<unsigned int>() + r_d * V1, (size_t)dirty * V1 * 4,
                               hipMemcpyDeviceToDevice, s));
+    // dense runs (sparse.h) hold one fp16 weight per doc of the range: every word of the rebuilt blocks starts as "absent /
+    // absent"; sparse runs and their fillers are overwritten whole by the two kernels below
+    {
+        const int64_t w0 = h->h_range_base[r_d], w1 = h->h_range_base[n_ranges];
+        if (w1 > w0)
+            HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)(h->post.as<uint32_t>() + w0), (int)0x80008000u, (size_t)(w1 - w0), s));
+    }
     // (the fill kernel permutes docs inside aligned blocks of 128: its grid covers whole blocks)
     hipLaunchKernelGGL(sparse_fill_kernel, dim3((unsigned)((round_up(n - doc0, 128) + 255) / 256)), dim3(256), 0, s, h->s_indptr.as<int64_t>(),
                        h->s_idx.as<int32_t>(), h->s_val.as<float>(), doc0, n, V1, tmp.cursor.as<unsigned int>(),
-                       h->range_base.as<int64_t>(), h->post.as<uint32_t>());
+                       h->rt_off.as<unsigned int>(), h->range_base.as<int64_t>(), h->post.as<uint32_t>());
     HIP_TRY(h, hipGetLastError());
     const int64_t pairs = dirty * h->sparse_dim;
     hipLaunchKernelGGL(sparse_pad_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s,
@@ -1095,6 +1115,8 @@ int build_sparse(hr_index* h) {
     HIP_TRY(h, hipStreamSynchronize(s));
     h->n_ranges = n_ranges;
     h->n_sparse_built = n;
+    h->n_dense_runs = 0;
+    for (unsigned c : h->h_range_dense) h->n_dense_runs += c;
     return HR_OK;
 }
 

@@ -12,6 +12,13 @@ namespace hbmrag {
 
 constexpr int kRangeDocs = 16384;                     // docs per range = LDS accumulator length (u16 local ids)
 constexpr int kScanTermChunk = 256;                   // query terms staged per pass
+// A term that at least half of a range's docs have is stored as a DENSE run: one fp16 weight per doc of the range, in doc
+// order (kRangeDocs / 2 posting words; 0x8000 = the doc does not have the term), instead of a 4-byte posting per doc that
+// has it — never longer than the sparse form, and the scan applies it without LDS atomics and without a slot table (the
+// thread that owns 32 consecutive docs adds the 32 products to its own accumulators).  On Zipfian postings these few runs are
+// most of a query's postings.  A run is dense iff its length is exactly kDenseRunWords: sparse runs are shorter.
+constexpr unsigned kDenseRunWords = kRangeDocs / 2;
+constexpr unsigned short kDenseAbsent = 0x8000u;      // -0.0: a stored weight of +/-0 is canonicalised to +0
 
 // ---- build: CSR (doc-major) -> range-major postings ---------------------------
 // rt_off[range][t] counts, then (after the per-range exclusive scan) offsets of
@@ -33,15 +40,19 @@ __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int*
                                                                    int64_t range0,
                                                                    unsigned long long* __restrict__ range_total) {
     __shared__ unsigned int wsum[16];
-    __shared__ unsigned int carry;
+    __shared__ unsigned int carry, n_dense;
     unsigned int* row = rt_off + (range0 + (int64_t)blockIdx.x) * V1;
     const int64_t V = V1 - 1;
-    if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x == 0) { carry = 0; n_dense = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t base = 0; base < V; base += blockDim.x) {
         int64_t i = base + threadIdx.x;
         unsigned int v = (i < V) ? (row[i] + 3u) & ~3u : 0u;
+        if (v >= kDenseRunWords) {   // half of the range's docs or more: the dense form
+            v = kDenseRunWords;
+            atomicAdd(&n_dense, 1u);
+        }
         unsigned int x = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(1024) void sparse_scan_offsets_kernel(unsigned int*
     }
     if (threadIdx.x == 0) {
         row[V] = carry;
-        range_total[blockIdx.x] = carry;
+        range_total[blockIdx.x] = (unsigned long long)carry | ((unsigned long long)n_dense << 32);   // words | dense runs
     }
 }
 
@@ -75,12 +86,15 @@ constexpr int kAccPadShift = 5;
 constexpr int kAccSlice = (1 << kAccPadShift) + 2;                 // words per 32-doc slice
 constexpr int kAccWords = (kRangeDocs >> kAccPadShift) * kAccSlice;
 __host__ __device__ inline int acc_slot(int local_doc) { return local_doc + 2 * (local_doc >> kAccPadShift); }
-__device__ inline uint32_t pack_posting(uint16_t local_doc, float w) {
+__device__ inline unsigned short posting_weight_bits(float w) {
     union { _Float16 h; unsigned short u; } cv;
     cv.h = (_Float16)w;  // round to nearest even
     unsigned short hb = cv.u;
     if ((hb & 0x7FFFu) == 0 && w != 0.f) hb = (unsigned short)((w < 0.f ? 0x8000u : 0u) | 1u);  // keep the sign, min subnormal
-    return ((uint32_t)hb << 16) | (uint32_t)acc_slot(local_doc);
+    return hb;
+}
+__device__ inline uint32_t pack_posting(uint16_t local_doc, float w) {
+    return ((uint32_t)posting_weight_bits(w) << 16) | (uint32_t)acc_slot(local_doc);
 }
 __device__ inline float posting_weight(uint32_t p) {
     union { _Float16 h; unsigned short u; } cv;
@@ -99,18 +113,27 @@ __device__ inline float posting_weight(uint32_t p) {
 // 4 apart, a 4-way bank conflict on every atomic (Zipfian corpora: 0.29 of the HBM peak before, see DESIGN).
 __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
                                    const float* __restrict__ val, int64_t doc0, int64_t n_docs, int64_t V1,
-                                   unsigned int* __restrict__ cursor, const int64_t* __restrict__ range_base,
-                                   uint32_t* __restrict__ post) {
+                                   unsigned int* __restrict__ cursor, const unsigned int* __restrict__ rt_off,
+                                   const int64_t* __restrict__ range_base, uint32_t* __restrict__ post) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t d = doc0 + (i & ~127ll) + 32 * (i & 3) + ((i >> 2) & 31);
     if (d >= n_docs) return;
     const int64_t range = d / kRangeDocs;
     unsigned int* cur = cursor + (range - doc0 / kRangeDocs) * V1;
+    const unsigned int* off = rt_off + range * V1;
     const int64_t base = range_base[range];
     const uint16_t local = (uint16_t)(d - range * kRangeDocs);
     for (int64_t e = indptr[d]; e < indptr[d + 1]; ++e) {
-        unsigned int slot = atomicAdd(&cur[idx[e]], 1u);
-        post[base + slot] = pack_posting(local, val[e]);
+        const int32_t t = idx[e];
+        const unsigned int lo = off[t];
+        if (off[t + 1] - lo == kDenseRunWords) {   // dense run: the doc's weight at its own place (the block was preset to "absent")
+            unsigned short hb = posting_weight_bits(val[e]);
+            if (hb == kDenseAbsent) hb = 0;         // a stored -0 counts like +0 (one unit, as in the sparse form)
+            reinterpret_cast<unsigned short*>(post + base + lo)[local] = hb;
+        } else {
+            unsigned int slot = atomicAdd(&cur[t], 1u);
+            post[base + slot] = pack_posting(local, val[e]);
+        }
     }
 }
 
@@ -125,6 +148,7 @@ __global__ void sparse_pad_kernel(const unsigned int* __restrict__ rt_off, const
     if (i >= (n_ranges - range0) * V) return;
     const int64_t rel = i / V, t = i - rel * V, range = range0 + rel;
     const unsigned int end = rt_off[range * V1 + t + 1];
+    if (end - rt_off[range * V1 + t] == kDenseRunWords) return;   // a dense run has no filler postings
     for (unsigned int p = cursor[rel * V1 + t]; p < end; ++p) post[range_base[range] + p] = filler_posting((unsigned int)t);
 }
 
@@ -212,6 +236,7 @@ constexpr int kScanK = 8;                               // items a wave keeps in
 constexpr int kSlotPostings = 64;                       // postings per slot (16 lanes x 4)
 constexpr int kSlots = kScanK * kScanWaves * 4;         // slots per step = everything one round of loads covers
 constexpr int kDocsPerThread = kRangeDocs / kScanThreads;  // consecutive docs a thread reduces in the group-max pass
+constexpr int kMaxDenseStep = 32;                       // dense runs one step may carry (more: the unit simply takes more steps)
 static_assert(kDocsPerThread == 32 && (1 << kAccPadShift) == kDocsPerThread, "one padded slice per thread");
 static_assert(kSlots >= kRangeDocs / kSlotPostings, "the longest possible run must fit an empty slot table");
 
@@ -228,6 +253,7 @@ struct ScanTab {
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load at 4-byte alignment
 
+template <bool DENSE>   // DENSE: the shard has dense runs (kDenseRunWords); without any, the code for them is compiled out
 __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_kernel(
     const unsigned int* __restrict__ rt_off, int64_t V1, const int64_t* __restrict__ range_base,
     const uint32_t* __restrict__ post, const int32_t* __restrict__ pq_n, const int32_t* __restrict__ pq_idx,
@@ -239,6 +265,11 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
     __shared__ ScanTab tab[2];  // T(s) lives in tab[s & 1]
     __shared__ unsigned run_first[kScanTermChunk], run_lo[kScanTermChunk], run_hi[kScanTermChunk];  // wave 0's scratch for long runs
     __shared__ float run_w[kScanTermChunk];
+    // dense runs of a step (see kDenseRunWords): offset inside the range's block and scaled query weight, in a ring of three
+    // steps — T(s + 2) is built while step s still reads its own
+    __shared__ unsigned dl_lo[3][kMaxDenseStep];
+    __shared__ float dl_w[3][kMaxDenseStep];
+    __shared__ int dl_n[3];
     // Block (x, y) = chunk y of query (x + y) mod B.  Workgroups go to the eight XCDs strictly round-robin in linear order
     // (tests/probes/xcd_dispatch_census.hip: workgroup L runs on XCD L % 8, also when the grid oversubscribes the chip) and
     // B is usually a multiple of 8: without the rotation XCD i would run queries i, i + 8, ... of EVERY chunk, and the XCD
@@ -285,49 +316,65 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         }
         base = (unsigned long long)range_base[r0 + range];
     };
-    auto p_build = [&](ScanTab& T) {  // the next step: as many whole runs of the current unit as fit the slot table
+    auto p_build = [&](ScanTab& T, int step_id) {  // the next step: as many whole runs of the current unit as fit the slot table
+        const int ring = step_id % 3;
         if (g_cur >= G) {
 #pragma unroll 1
             for (int i = lane; i < kSlots; i += 64) T.n[i] = 0u;
-            if (lane == 0) { T.n_slots = 0; T.range_done = 0; T.end = 1; T.base = 0; }
+            if (lane == 0) { T.n_slots = 0; T.range_done = 0; T.end = 1; T.base = 0; dl_n[ring] = 0; }
             return;
         }
         const int range = g_cur / n_chunks, chunk = g_cur - range * n_chunks;
         const int nt = min(kScanTermChunk, max(n_terms - chunk * kScanTermChunk, 0));
-        unsigned cnt[4], mine = 0;
+        unsigned cnt[4], dns[4], mine = 0, mine_d = 0;   // slots / dense-list entries of the lane's four runs
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int t = 4 * lane + j;
-            cnt[j] = (t >= p_pos && t < nt) ? (hic[j] - loc[j] + kSlotPostings - 1) / kSlotPostings : 0u;
+            const bool in_unit = t >= p_pos && t < nt;
+            const unsigned len = hic[j] - loc[j];
+            dns[j] = (DENSE && in_unit && len == kDenseRunWords) ? 1u : 0u;   // applied by the docs' owner threads, not through slots
+            cnt[j] = (in_unit && !dns[j]) ? (len + kSlotPostings - 1) / kSlotPostings : 0u;
             mine += cnt[j];
+            mine_d += dns[j];
         }
         const unsigned incl = wave_scan_add(mine);
         unsigned first = incl - mine;
+        unsigned first_d = wave_scan_add(mine_d) - mine_d;
         unsigned taken = 0;  // term slots of this lane that go into the step
         unsigned used = 0;   // slots this lane's runs add to the step
+        unsigned used_d = 0; // dense-list entries this lane's runs add to the step
         unsigned longest = 0;
-        auto run_fits = [&](int j, unsigned start) {  // run j of this lane is in range and still fits the step's slot table
+        // run j of this lane is in range and still fits the step's slot table and dense list; both prefixes are monotone
+        auto run_fits = [&](int j, unsigned start, unsigned dstart) {
             const int t = 4 * lane + j;
-            return t >= p_pos && t < nt && start + cnt[j] <= (unsigned)kSlots;
+            return t >= p_pos && t < nt && start + cnt[j] <= (unsigned)kSlots && dstart + dns[j] <= (unsigned)kMaxDenseStep;
         };
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (run_fits(j, first)) {
+            if (run_fits(j, first, first_d)) {
                 ++taken;
                 used += cnt[j];
+                used_d += dns[j];
                 longest = max(longest, cnt[j]);
+                if (dns[j]) {
+                    dl_lo[ring][first_d] = loc[j];
+                    dl_w[ring][first_d] = wc[j];
+                }
             }
             first += cnt[j];
+            first_d += dns[j];
         }
         first -= mine;
+        first_d -= mine_d;
         // the prefix is monotone, so the runs that fit are exactly the first ones: their slot counts simply add up
         taken = wave_sum(taken);
         used = wave_sum(used);
+        used_d = wave_sum(used_d);
         if (!__any(longest > 8u)) {
             // short runs (the usual case: ~3 slots each): every lane writes the slots of its own runs
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (run_fits(j, first)) {
+                if (run_fits(j, first, first_d)) {
                     unsigned e = loc[j];
 #pragma unroll 1
                     for (unsigned c = 0; c < cnt[j]; ++c, e += kSlotPostings) {
@@ -337,6 +384,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
                     }
                 }
                 first += cnt[j];
+                first_d += dns[j];
             }
         } else {
             // a long run (a frequent term: up to 256 slots) would keep ONE lane writing for thousands of cycles between
@@ -375,6 +423,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
             T.base = base_c;
             T.range_done = unit_done && chunk == n_chunks - 1;
             T.end = 0;
+            dl_n[ring] = (int)used_d;
         }
         p_pos = p_end;
         if (unit_done) {  // on to the next unit; request the bounds of the one after it
@@ -427,7 +476,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         p_issue(0, loc, hic, wc, base_c);
         if (G > 1) p_issue(1, lon, hin, wn, base_n);
 #pragma unroll 1
-        for (int i = 0; i < 2; ++i) p_build(tab[i]);
+        for (int i = 0; i < 2; ++i) p_build(tab[i], i);
     }
     __syncthreads();
     u32x4_a4 pk[K];
@@ -446,6 +495,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         const int n_c = Tc.n_slots;
         const bool range_done = Tc.range_done != 0;
         const int64_t range = r0 + Tc.range;
+        const uint32_t* pp_c = post + Tc.base;   // read now: T(s) is rebuilt as T(s + 2) behind the barrier
         const uint32_t* pp_n = post + Tn.base;
         // apply item u of step s, refill the quad with item u of step s+1
 #pragma unroll
@@ -455,7 +505,37 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
             pk[u] = load_item(Tn, pp_n, item);  // unconditional (an item past the step reads the block's first bytes): no branch around the load
         }
         __syncthreads();  // every posting of step s is in the accumulators; T(s) is free
-        if (wave == 0) p_build(tab[s & 1]);  // T(s+2)
+        // dense runs of the step: no atomics are in flight between the two barriers, so the thread that owns 32 consecutive
+        // docs adds their products to its own accumulators with plain read-modify-writes (two docs per 64-bit word), 16
+        // bytes (8 docs) at a time to keep the registers of the posting pipeline where they are
+        if (DENSE && dl_n[s % 3] > 0) {
+            const int ring = s % 3, nd = dl_n[ring];
+            unsigned long long* mine = reinterpret_cast<unsigned long long*>(acc + tid * kAccSlice);
+            // pieces (run d, quarter q) in one software-pipelined loop: piece p + 1 is requested before piece p is applied
+            auto piece = [&](int pi) -> u32x4_a4 {
+                return *reinterpret_cast<const u32x4_a4*>(pp_c + dl_lo[ring][pi >> 2] + 16 * tid + 4 * (pi & 3));
+            };
+            const int n_pieces = 4 * nd;
+            u32x4_a4 r = piece(0);
+#pragma unroll 1
+            for (int pi = 0; pi < n_pieces; ++pi) {
+                const u32x4_a4 rn = piece(pi + 1 < n_pieces ? pi + 1 : pi);
+                const float wr = dl_w[ring][pi >> 2];
+                const int q = pi & 3;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w2 = r[k];
+                    const unsigned short h0 = (unsigned short)(w2 & 0xFFFFu), h1 = (unsigned short)(w2 >> 16);
+                    const int c0 = h0 != kDenseAbsent ? (int)fmaf(posting_weight((uint32_t)h0 << 16), wr, 1.0f) : 0;
+                    const int c1 = h1 != kDenseAbsent ? (int)fmaf(posting_weight((uint32_t)h1 << 16), wr, 1.0f) : 0;
+                    const unsigned long long x = mine[4 * q + k];
+                    mine[4 * q + k] = (unsigned long long)(unsigned)((int)(unsigned)x + c0) |
+                                      ((unsigned long long)(unsigned)((int)(unsigned)(x >> 32) + c1) << 32);
+                }
+                r = rn;
+            }
+        }
+        if (wave == 0) p_build(tab[s & 1], s + 2);  // T(s+2)
         if (range_done) {
             // per-group maxima of the finished range, and zero for the next one: a thread owns DPT consecutive docs
             const int64_t doc0 = range * kRangeDocs + (int64_t)tid * DPT;

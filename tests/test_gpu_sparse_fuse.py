@@ -220,3 +220,50 @@ def test_zipfian_postings_and_long_queries_match_oracle(gpu):
     assert d_fl.min().item() == 1
     assert np.array_equal(d_ids.cpu().numpy(), oids)
     h.close()
+
+
+def test_dense_run_format_boundaries_and_appends(gpu):
+    """The dense form of frequent terms' runs (csrc/sparse.h: one fp16 weight per doc of a range when at least 8 189 of the
+    range's 16 384 docs have the term): 50 terms in EVERY doc (more dense runs in one query than a step's list holds: 32),
+    terms at exactly 8 188 / 8 189 / 8 192 / 8 193 docs of the first range (last sparse and first dense lengths), zero
+    weights and tiny weights among the dense ones, a partial second range in which the same terms are sparse again — and
+    the shard grown by appends, so that runs switch form when a flush rebuilds their range.  Every state against the
+    oracle, bit for bit."""
+    rng = np.random.default_rng(23)
+    n, V = 20000, 300
+    rows_idx, rows_val = [], []
+    special = {60: 8188, 61: 8189, 62: 8192, 63: 8193}
+    member = {t: set(rng.choice(16384, c, replace=False).tolist()) for t, c in special.items()}
+    for d in range(n):
+        terms = list(range(50))                                             # in every doc
+        terms += [t for t in special if d in member[t]]                     # counted inside range 0 only
+        terms += (100 + rng.choice(200, 6, replace=False)).tolist()         # ordinary sparse terms
+        terms = np.unique(np.asarray(terms, dtype=np.int32))
+        w = np.abs(rng.standard_normal(terms.shape[0])).astype(np.float32) + 0.01
+        if d % 977 == 0:
+            w[0] = 0.0                                                      # a stored zero weight in a dense run
+        if d % 1009 == 0:
+            w[1] = 1e-9                                                     # rounds to the smallest fp16 subnormal
+        rows_idx.append(terms)
+        rows_val.append(w)
+    ptr = np.concatenate([[0], np.cumsum([len(r) for r in rows_idx])]).astype(np.int64)
+    idx, val = np.concatenate(rows_idx), np.concatenate(rows_val)
+    queries = [(np.arange(50, dtype=np.int32), np.abs(rng.standard_normal(50)).astype(np.float32) + 0.1),      # 50 dense runs
+               (np.array([3, 60, 61, 62, 63, 150], np.int32), np.array([0.5, 1.0, 1.0, 1.0, 1.0, 2.0], np.float32)),
+               (np.array([0, 1, 120, 130], np.int32), np.array([1.0, 1.0, 3.0, 3.0], np.float32)),
+               (np.arange(0, 300, 3, dtype=np.int32), np.abs(rng.standard_normal(100)).astype(np.float32))]
+    h = nat.ShardHandle(0, sparse_dim=V)
+    done = 0
+    for upto in (5000, 9000, 16384, 16500, n):   # 5 000 / 9 000 docs: "every doc" terms switch from sparse to dense in range 0
+        h.add_sparse(ptr[done: upto + 1] - ptr[done], idx[ptr[done]: ptr[upto]], val[ptr[done]: ptr[upto]])
+        h.finalize()
+        done = upto
+        ids, sc = h.search_sparse(queries, 40)
+        oids, osc = oracle.sparse_search(ptr[: upto + 1], idx[: ptr[upto]], val[: ptr[upto]], queries, 40)
+        assert np.array_equal(ids, oids), upto
+        assert np.array_equal(_bits(sc), _bits(osc)), upto
+    mask = np.packbits(rng.random(n) < 0.4, bitorder="little")
+    ids, sc = h.search_sparse(queries, 40, 0.0, mask)
+    oids, osc = oracle.sparse_search(ptr, idx, val, queries, 40, 0.0, mask)
+    assert np.array_equal(ids, oids) and np.array_equal(_bits(sc), _bits(osc))
+    h.close()
