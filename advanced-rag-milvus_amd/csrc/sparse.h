@@ -233,12 +233,16 @@ __global__ __launch_bounds__(256) void sparse_query_prep_kernel(const int64_t* _
 constexpr int kScanThreads = 512;
 constexpr int kScanWaves = kScanThreads / 64;
 constexpr int kScanK = 8;                               // items a wave keeps in flight
+constexpr int kScanKDense = 4;                          // ... in the variant for shards with dense runs: its 16 registers hold four
+                                                        // 16-byte pieces of dense runs in flight instead (the longest SPARSE run of
+                                                        // such a shard is < 8 189 postings = 128 slots: the smaller table holds it)
 constexpr int kSlotPostings = 64;                       // postings per slot (16 lanes x 4)
 constexpr int kSlots = kScanK * kScanWaves * 4;         // slots per step = everything one round of loads covers
 constexpr int kDocsPerThread = kRangeDocs / kScanThreads;  // consecutive docs a thread reduces in the group-max pass
 constexpr int kMaxDenseStep = 32;                       // dense runs one step may carry (more: the unit simply takes more steps)
 static_assert(kDocsPerThread == 32 && (1 << kAccPadShift) == kDocsPerThread, "one padded slice per thread");
 static_assert(kSlots >= kRangeDocs / kSlotPostings, "the longest possible run must fit an empty slot table");
+static_assert(kScanKDense * kScanWaves * 4 >= (int)kDenseRunWords / kSlotPostings, "the longest sparse run must fit the dense variant's table");
 
 struct ScanTab {
     unsigned e0[kSlots];      // per slot: first posting, relative to the range's block
@@ -260,7 +264,8 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
     const float* __restrict__ pq_w, int stride, const float* __restrict__ q_scale,
     const uint8_t* __restrict__ rowmask, int64_t n_docs, int64_t n_groups, int group_docs, int64_t n_ranges,
     int rpb, const uint32_t* __restrict__ idle_postings, float* __restrict__ gmax) {
-    constexpr int K = kScanK, NW = kScanWaves, DPT = kDocsPerThread;
+    constexpr int K = DENSE ? kScanKDense : kScanK, NW = kScanWaves, DPT = kDocsPerThread;
+    constexpr int kSlotsV = K * NW * 4;   // slots per step of this variant (the tables are sized for the larger one)
     __shared__ int acc[kAccWords];
     __shared__ ScanTab tab[2];  // T(s) lives in tab[s & 1]
     __shared__ unsigned run_first[kScanTermChunk], run_lo[kScanTermChunk], run_hi[kScanTermChunk];  // wave 0's scratch for long runs
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         const int ring = step_id % 3;
         if (g_cur >= G) {
 #pragma unroll 1
-            for (int i = lane; i < kSlots; i += 64) T.n[i] = 0u;
+            for (int i = lane; i < kSlotsV; i += 64) T.n[i] = 0u;
             if (lane == 0) { T.n_slots = 0; T.range_done = 0; T.end = 1; T.base = 0; dl_n[ring] = 0; }
             return;
         }
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         // run j of this lane is in range and still fits the step's slot table and dense list; both prefixes are monotone
         auto run_fits = [&](int j, unsigned start, unsigned dstart) {
             const int t = 4 * lane + j;
-            return t >= p_pos && t < nt && start + cnt[j] <= (unsigned)kSlots && dstart + dns[j] <= (unsigned)kMaxDenseStep;
+            return t >= p_pos && t < nt && start + cnt[j] <= (unsigned)kSlotsV && dstart + dns[j] <= (unsigned)kMaxDenseStep;
         };
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
             }
         }
 #pragma unroll 1
-        for (int i = (int)used + lane; i < kSlots; i += 64) T.n[i] = 0u;  // unused slots fetch idle postings
+        for (int i = (int)used + lane; i < kSlotsV; i += 64) T.n[i] = 0u;  // unused slots fetch idle postings
         const int p_end = p_pos + (int)taken;
         const bool unit_done = p_end >= nt;
         if (lane == 0) {
@@ -511,28 +516,32 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         if (DENSE && dl_n[s % 3] > 0) {
             const int ring = s % 3, nd = dl_n[ring];
             unsigned long long* mine = reinterpret_cast<unsigned long long*>(acc + tid * kAccSlice);
-            // pieces (run d, quarter q) in one software-pipelined loop: piece p + 1 is requested before piece p is applied
-            auto piece = [&](int pi) -> u32x4_a4 {
-                return *reinterpret_cast<const u32x4_a4*>(pp_c + dl_lo[ring][pi >> 2] + 16 * tid + 4 * (pi & 3));
+            // four 16-byte pieces (the quarters of a run) in flight: quarter q of the next run is requested right after
+            // quarter q of this one has been applied — the registers are the ones the posting pipeline gave up (kScanKDense)
+            auto piece = [&](int d, int q) -> u32x4_a4 {
+                return *reinterpret_cast<const u32x4_a4*>(pp_c + dl_lo[ring][d] + 16 * tid + 4 * q);
             };
-            const int n_pieces = 4 * nd;
-            u32x4_a4 r = piece(0);
-#pragma unroll 1
-            for (int pi = 0; pi < n_pieces; ++pi) {
-                const u32x4_a4 rn = piece(pi + 1 < n_pieces ? pi + 1 : pi);
-                const float wr = dl_w[ring][pi >> 2];
-                const int q = pi & 3;
+            u32x4_a4 r[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint32_t w2 = r[k];
-                    const unsigned short h0 = (unsigned short)(w2 & 0xFFFFu), h1 = (unsigned short)(w2 >> 16);
-                    const int c0 = h0 != kDenseAbsent ? (int)fmaf(posting_weight((uint32_t)h0 << 16), wr, 1.0f) : 0;
-                    const int c1 = h1 != kDenseAbsent ? (int)fmaf(posting_weight((uint32_t)h1 << 16), wr, 1.0f) : 0;
-                    const unsigned long long x = mine[4 * q + k];
-                    mine[4 * q + k] = (unsigned long long)(unsigned)((int)(unsigned)x + c0) |
-                                      ((unsigned long long)(unsigned)((int)(unsigned)(x >> 32) + c1) << 32);
+            for (int q = 0; q < 4; ++q) r[q] = piece(0, q);
+#pragma unroll 1
+            for (int d = 0; d < nd; ++d) {
+                const float wr = dl_w[ring][d];
+                const int dn = d + 1 < nd ? d + 1 : d;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t w2 = r[q][k];
+                        const unsigned short h0 = (unsigned short)(w2 & 0xFFFFu), h1 = (unsigned short)(w2 >> 16);
+                        const int c0 = h0 != kDenseAbsent ? (int)fmaf(posting_weight((uint32_t)h0 << 16), wr, 1.0f) : 0;
+                        const int c1 = h1 != kDenseAbsent ? (int)fmaf(posting_weight((uint32_t)h1 << 16), wr, 1.0f) : 0;
+                        const unsigned long long x = mine[4 * q + k];
+                        mine[4 * q + k] = (unsigned long long)(unsigned)((int)(unsigned)x + c0) |
+                                          ((unsigned long long)(unsigned)((int)(unsigned)(x >> 32) + c1) << 32);
+                    }
+                    r[q] = piece(dn, q);
                 }
-                r = rn;
             }
         }
         if (wave == 0) p_build(tab[s & 1], s + 2);  // T(s+2)
