@@ -597,7 +597,7 @@ def main():
             # the algorithmic figure prices every posting at 4 bytes; the runs of terms that at least half of a range's docs
             # have are STORED at 2 bytes per doc of the range (csrc/sparse.h), so on this corpus the scan fetches less than
             # it is credited with and `frac` can pass what the memory system can deliver: read it as a speed in
-            # postings, not as a bandwidth (the r2 PMC file under `traffic` predates the dense form)
+            # postings, not as a bandwidth (`traffic` is what it really moves: profiles/r3_pmc_traffic_zipf.json)
             sparse_roof["note"] = "4 B per posting credited; frequent terms' runs are stored at 2 B per doc (dense form)"
 
     # ---- p50 latency of single-query retrieve() through the Python API ---------------------------------------------
