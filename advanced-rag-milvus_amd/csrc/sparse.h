@@ -601,9 +601,9 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
 // row with a 400-byte stride between lanes and thrashed the L1: 0.97 ms per 128-query
 // batch against the scans it shares the chip with.)
 constexpr int kFilterBits = 32768;
-constexpr int kRefinePrefetch = 8;   // docs whose entries a wave has in flight: the chain is bound by memory latency (two
+constexpr int kRefinePrefetch = 12;  // docs whose entries a wave has in flight: the chain is bound by memory latency (two
                                      // dependent round trips per doc), so depth buys time almost linearly until the
-                                     // per-doc filter test + ballot (~100 cycles) is what is left (2 -> 8: r3 probe)
+                                     // per-doc filter test + ballot (~100 cycles) is what is left (2 -> 8: r3 probe; 8 -> 12: the last 2 %, same registers)
 
 // Stage query qi in LDS for the refine: s_filter (kFilterBits / 32 words), s_idx / s_val (q_cap entries each).
 // All threads of the block take part; returns the number of staged terms.
