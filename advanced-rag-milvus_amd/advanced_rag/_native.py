@@ -452,7 +452,7 @@ class PostArgs(ctypes.Structure):
         ("method_bonus", _c.c_double), ("recency_w", _c.c_double), ("recency", _c.c_void_p), ("k_out", _c.c_int32),
         ("reserved", _c.c_int32), ("rr_ids", _c.c_void_p), ("rr_scores", _c.c_void_p), ("rr_orig", _c.c_void_p),
         ("flags", _c.c_void_p), ("flag_stride", _c.c_int64), ("n_flag_rows", _c.c_int32), ("reserved2", _c.c_int32),
-        ("agg_flags", _c.c_void_p),
+        ("agg_flags", _c.c_void_p), ("w_query", _c.c_void_p),
     ]
 
 

@@ -31,6 +31,25 @@ import numpy as np
 from .engine import pack_sparse_queries
 
 
+def _deliver(fut: Future, value) -> None:
+    """Hand a result to a caller that may be gone: a request whose awaiting coroutine timed out or was cancelled has a
+    cancelled Future (asyncio.wrap_future propagates it), and set_result on it raises InvalidStateError — which must
+    never reach the other requests of the batch."""
+    try:
+        if not fut.done():
+            fut.set_result(value)
+    except Exception:   # InvalidStateError: cancelled between the check and the call
+        pass
+
+
+def _fail(fut: Future, exc: BaseException) -> None:
+    try:
+        if not fut.done():
+            fut.set_exception(exc)
+    except Exception:
+        pass
+
+
 @dataclass
 class _Request:
     kind: str                 # "dense" | "sparse" | "fuse"
@@ -58,7 +77,8 @@ class SearchCoalescer:
         self.collective = hasattr(getattr(manager, "_main", None), "round")
         self.stats = {"rounds": 0, "requests": 0, "dense_launches": 0, "sparse_launches": 0, "fuse_launches": 0,
                       "hybrid_launches": 0, "max_batch_seen": 0, "redone_unproven": 0, "busy_s": 0.0}
-        self._engines: Dict[Tuple, Any] = {}   # hybrid engines per (top_k, weights, rrf_k)
+        self._engines: Dict[Tuple, Any] = {}   # hybrid engines per (top_k, rrf_k)
+        self._inflight: List[_Request] = []    # the requests of the round in progress (failed as a whole if the worker dies)
 
     # ------------------------------------------------------------------ front
     def submit(self, kind: str, key: Tuple, payload: Any) -> Future:
@@ -66,12 +86,34 @@ class SearchCoalescer:
         with self._lock:
             if self._closed:
                 raise RuntimeError("search front is closed")
-            if self._thread is None:
-                self._thread = threading.Thread(target=self._run_collective if self.collective else self._run,
-                                                name="search-coalescer", daemon=True)
+            if self._thread is None or not self._thread.is_alive():   # first request, or the worker died: start one
+                self._thread = threading.Thread(target=self._guarded, name="search-coalescer", daemon=True)
                 self._thread.start()
         self._q.put(req)
         return req.future
+
+    def _guarded(self):
+        """The worker loop with a last line of defence: whatever escapes a round (a HIP error from a stream
+        synchronisation, a bug) fails every request that is still waiting — nobody hangs — and ends this thread; the
+        next submit() starts a fresh one."""
+        self._inflight: List[_Request] = []
+        try:
+            (self._run_collective if self.collective else self._run)()
+        except BaseException as e:   # noqa: BLE001 - the callers must hear about it, whatever it was
+            self.stats["worker_failures"] = self.stats.get("worker_failures", 0) + 1
+            err = RuntimeError(f"search front worker failed: {type(e).__name__}: {e}")
+            for r in self._inflight:
+                _fail(r.future, err)
+            while True:
+                try:
+                    r = self._q.get_nowait()
+                except queue.Empty:
+                    break
+                if r is not None:
+                    _fail(r.future, err)
+            with self._lock:
+                if self._thread is threading.current_thread():
+                    self._thread = None
 
     def close(self):
         with self._lock:
@@ -106,7 +148,12 @@ class SearchCoalescer:
                 self._q.put(None)  # close() arrived behind real work: finish this round first
                 break
             reqs.append(r)
-        return reqs
+        # claim the futures: a request cancelled while it waited in the queue is dropped here, and one that is claimed
+        # can no longer be cancelled under the worker's feet (Future.cancel() fails on a running future)
+        live = [r for r in reqs if r.future.set_running_or_notify_cancel()]
+        self.stats["cancelled_before_launch"] = self.stats.get("cancelled_before_launch", 0) + len(reqs) - len(live)
+        self._inflight = live
+        return live
 
     def _run(self):
         import torch
@@ -118,6 +165,8 @@ class SearchCoalescer:
             reqs = self._collect()
             if reqs is None:
                 return
+            if not reqs:
+                continue
             t0 = time.perf_counter()
             groups: Dict[Tuple, List[_Request]] = {}
             for r in reqs:
@@ -145,10 +194,10 @@ class SearchCoalescer:
                     continue
                 try:
                     getattr(self, "_scatter_" + kind)(key, chunk, state)
-                except Exception as e:  # pragma: no cover - defensive: never leave a caller waiting
+                except Exception as e:  # never leave a caller waiting
                     for r in chunk:
-                        if not r.future.done():
-                            r.future.set_exception(e)
+                        _fail(r.future, e)
+            self._inflight = []
             self.stats["busy_s"] += time.perf_counter() - t0
 
     def _run_collective(self):
@@ -162,6 +211,8 @@ class SearchCoalescer:
             reqs = self._collect()
             if reqs is None:
                 return
+            if not reqs:
+                continue
             t0 = time.perf_counter()
             self.stats["rounds"] += 1
             self.stats["requests"] += len(reqs)
@@ -169,11 +220,19 @@ class SearchCoalescer:
             for r in reqs:
                 if r.kind == "fuse":
                     try:
-                        r.future.set_result(self.mgr._fuse_rows_blocking(r.payload, r.key))
+                        _deliver(r.future, self.mgr._fuse_rows_blocking(r.payload, r.key))
                     except Exception as e:
-                        r.future.set_exception(e)
+                        _fail(r.future, e)
                     continue
                 coll_name, top_k, expr, params_key = r.key
+                if self.mgr.collections[coll_name].handle is not cs:
+                    # a collection that is NOT spread over the ranks (the local domain shard): its searches have nothing
+                    # to do with the shard set's rounds — the blocking single-shard path answers them
+                    try:
+                        _deliver(r.future, self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
+                    except Exception as e:
+                        _fail(r.future, e)
+                    continue
                 drop = float(dict(params_key).get("drop_ratio_search", 0.0)) if r.kind == "sparse" else None
                 groups.setdefault((top_k, expr), {}).setdefault((r.kind, drop), []).append(r)
             for (top_k, expr), by_kind in groups.items():
@@ -195,11 +254,11 @@ class SearchCoalescer:
                             self.stats["max_batch_seen"] = max(self.stats["max_batch_seen"], len(d_chunk), len(s_chunk))
                             for chunk, lists in ((d_chunk, res[0]), (s_chunk, res[1])):
                                 for i, r in enumerate(chunk):
-                                    r.future.set_result((lists[0][i], lists[1][i]))
+                                    _deliver(r.future, (lists[0][i], lists[1][i]))
                         except Exception as e:
                             for r in d_chunk + s_chunk:
-                                if not r.future.done():
-                                    r.future.set_exception(e)
+                                _fail(r.future, e)
+            self._inflight = []
             self.stats["busy_s"] += time.perf_counter() - t0
 
     def _one_by_one(self, kind: str, key: Tuple, chunk: List[_Request]):
@@ -208,14 +267,14 @@ class SearchCoalescer:
         for r in chunk:
             try:
                 if kind == "fuse":
-                    r.future.set_result(self.mgr._fuse_rows_blocking(r.payload, key))
+                    _deliver(r.future, self.mgr._fuse_rows_blocking(r.payload, key))
                 elif kind == "hybrid":
-                    r.future.set_result(None)   # the caller falls back to two searches + a fusion
+                    _deliver(r.future, None)   # the caller falls back to two searches + a fusion
                 else:
                     coll_name, top_k, expr, params_key = key
-                    r.future.set_result(self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
+                    _deliver(r.future, self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
             except Exception as e:
-                r.future.set_exception(e)
+                _fail(r.future, e)
 
     # ------------------------------------------------------------------ dense
     def _enqueue_dense(self, torch, dev, stream, key, chunk):
@@ -271,27 +330,29 @@ class SearchCoalescer:
             try:
                 if fl[i] != 1:  # ties at the candidate cut: the host form widens the candidate set until the proof holds
                     self.stats["redone_unproven"] += 1
-                    r.future.set_result(self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
+                    _deliver(r.future, self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
                 else:
-                    r.future.set_result((ids[i], sc[i]))
+                    _deliver(r.future, (ids[i], sc[i]))
             except Exception as e:
-                r.future.set_exception(e)
+                _fail(r.future, e)
 
     # ------------------------------------------------------------------ hybrid (both searches + RRF of a request)
     def _enqueue_hybrid(self, torch, dev, stream, key, chunk):
         from .engine import EngineConfig, HybridSearchEngine
-        top_k, expr, drop, dw, sw, rrf_k = key
+        top_k, expr, drop, rrf_k = key
         handle = self.mgr.collections["semantic_index"].handle.first
-        ekey = (top_k, dw, sw, rrf_k)
+        ekey = (top_k, rrf_k)
         eng = self._engines.get(ekey)
         if eng is None:
-            if len(self._engines) >= 16:     # weight adapters can produce many weight pairs: keep the buffers bounded
+            if len(self._engines) >= 16:
                 self._engines.clear()
             eng = self._engines[ekey] = HybridSearchEngine(
-                handle, EngineConfig(top_k=top_k, dense_weight=dw, sparse_weight=sw, rrf_k=rrf_k, enable_reranking=False),
-                device=str(dev))
+                handle, EngineConfig(top_k=top_k, rrf_k=rrf_k, enable_reranking=False), device=str(dev))
         B = len(chunk)
         dense = [r.payload[0] for r in chunk]
+        # the fusion weights are per REQUEST (a weight_adapter may pick them per query, reference retrieval.py:251-262):
+        # they travel as a [B, 3] operand of the post kernel, so requests with different weights still share the round
+        wq = torch.from_numpy(np.array([[r.payload[2], r.payload[3], 0.0] for r in chunk], dtype=np.float64)).to(dev)
         if all(hasattr(q, "is_cuda") and q.is_cuda for q in dense):
             q = torch.stack([x.reshape(-1).to(torch.float32) for x in dense]).contiguous()
         else:
@@ -305,14 +366,14 @@ class SearchCoalescer:
             raise ValueError("no sparse terms in the batch")   # -> one by one through the general path
         d_sparse = (torch.from_numpy(ptr).to(dev), torch.from_numpy(idx).to(dev), torch.from_numpy(val).to(dev), int(max_nnz))
         mask = self.mgr._device_row_mask(expr, "dense")
-        b = eng.search(q, d_sparse, rowmask=mask)
+        b = eng.search(q, d_sparse, rowmask=mask, weights=wq)
         self.stats["hybrid_launches"] += 1
         self.stats["dense_launches"] += 1
         self.stats["sparse_launches"] += 1
         # the engine reuses ONE buffer set per batch size: another group (or the next chunk of this one) with the same B
         # is enqueued before this round is read back, so the results are copied out here, in stream order
         out = {k: b[k].clone() for k in ("fused_ids", "fused_scores", "fused_methods", "fused_n", "ids", "scores", "flags")}
-        return {"b": out, "keep": (q, d_sparse, mask)}
+        return {"b": out, "keep": (q, d_sparse, mask, wq)}
 
     def _scatter_hybrid(self, key, chunk, st):
         b = st["b"]
@@ -329,10 +390,10 @@ class SearchCoalescer:
         for i, r in enumerate(chunk):
             if not proven[i]:   # ties at a candidate cut: the general path redoes the searches through the host forms
                 self.stats["redone_unproven"] += 1
-                r.future.set_result(None)
+                _deliver(r.future, None)
                 continue
             n = int(fn[i])
-            r.future.set_result((fi[i, :n].copy(), fs[i, :n].copy(), fm[i, :n].copy(), orig[i, :n].copy()))
+            _deliver(r.future, (fi[i, :n].copy(), fs[i, :n].copy(), fm[i, :n].copy(), orig[i, :n].copy()))
 
     # ------------------------------------------------------------------ fuse
     def _enqueue_fuse(self, torch, dev, stream, key, chunk):
@@ -366,4 +427,4 @@ class SearchCoalescer:
         oi, os_, om, on = st["oi"].cpu().numpy(), st["os"].cpu().numpy(), st["om"].cpu().numpy(), st["on"].cpu().numpy()
         for i, r in enumerate(chunk):
             n = int(on[i])
-            r.future.set_result((oi[i, :n].copy(), os_[i, :n].copy(), om[i, :n].copy()))
+            _deliver(r.future, (oi[i, :n].copy(), os_[i, :n].copy(), om[i, :n].copy()))

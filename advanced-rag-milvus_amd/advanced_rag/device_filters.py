@@ -137,23 +137,27 @@ class DeviceFilters:
             bits[: packed.size] = packed
             d_del = torch.from_numpy(bits).to(dev)
         st = stream if stream is not None else torch.cuda.current_stream(dev)
-        nat.filter_eval_dev(terms, n_rows, d_del.data_ptr() if d_del is not None else 0, mask.data_ptr(), und.data_ptr(),
-                            counts.data_ptr(), st.cuda_stream)
-        kept, undecided = (int(x) for x in counts.cpu().tolist())   # synchronises the stream
-        self.stats["evaluations"] += 1
-        if undecided:
-            # rows that tie with a literal on the first 16 bytes: every other term has already passed them; settle the
-            # string terms on the full strings (host) and switch the survivors on
-            self.stats["undecided_rows"] += undecided
-            rows = np.nonzero(np.unpackbits(und.cpu().numpy(), bitorder="little")[:n_rows])[0]
-            ok = np.ones(rows.shape[0], dtype=bool)
-            for col_name, op, value in string_terms:
-                ok &= self.columns[col_name].compare_rows(rows, op, value)
-            rows = rows[ok]
-            kept += int(rows.shape[0])
-            for b in range(8):   # rows with the same bit position touch distinct bytes: plain indexed updates
-                sel = rows[(rows & 7) == b]
-                if sel.size:
-                    idx = torch.from_numpy(sel >> 3).to(dev)
-                    mask[idx] = mask[idx] | (1 << b)
+        with torch.cuda.stream(st):   # the read-backs and the fix-ups below are ordered behind the kernel on ITS stream
+            nat.filter_eval_dev(terms, n_rows, d_del.data_ptr() if d_del is not None else 0, mask.data_ptr(), und.data_ptr(),
+                                counts.data_ptr(), st.cuda_stream)
+            kept, undecided = (int(x) for x in counts.cpu().tolist())   # synchronises the stream
+            self.stats["evaluations"] += 1
+            if undecided:
+                # rows that tie with a literal on the first 16 bytes: every other term has already passed them; settle the
+                # string terms on the full strings (host) and switch the survivors on
+                self.stats["undecided_rows"] += undecided
+                rows = np.nonzero(np.unpackbits(und.cpu().numpy(), bitorder="little")[:n_rows])[0]
+                ok = np.ones(rows.shape[0], dtype=bool)
+                for col_name, op, value in string_terms:
+                    ok &= self.columns[col_name].compare_rows(rows, op, value)
+                rows = rows[ok]
+                kept += int(rows.shape[0])
+                for b in range(8):   # rows with the same bit position touch distinct bytes: plain indexed updates
+                    sel = rows[(rows & 7) == b]
+                    if sel.size:
+                        idx = torch.from_numpy(sel >> 3).to(dev)
+                        mask[idx] = mask[idx] | (1 << b)
+                # the mask is cached and handed to searches on OTHER streams (the front's dense / sparse / hybrid streams,
+                # the host view of _row_mask): only a finished mask may leave this function
+                st.synchronize()
         return mask, kept

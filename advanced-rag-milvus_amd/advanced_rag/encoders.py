@@ -237,13 +237,17 @@ def use_recorded_gemm_solutions() -> bool:
     if _TUNED_GEMMS is None:
         _TUNED_GEMMS = False
         try:
+            import atexit
             import os
             import shutil
             import tempfile
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950_minilm.csv")
             if torch.cuda.is_available() and os.path.exists(path):
-                # TunableOp may rewrite its results file when the process ends: it gets a private copy
-                work = os.path.join(tempfile.gettempdir(), f"hbmrag_tunableop_{os.getpid()}.csv")
+                # TunableOp may rewrite its results file when the process ends: it gets a private copy in a directory
+                # only this user can enter (mkdtemp: mode 0700, unpredictable name), removed when the process exits
+                private = tempfile.mkdtemp(prefix="hbmrag_tunableop_")
+                atexit.register(shutil.rmtree, private, ignore_errors=True)
+                work = os.path.join(private, "solutions.csv")
                 shutil.copyfile(path, work)
                 torch.cuda.tunable.enable(True)
                 torch.cuda.tunable.tuning_enable(False)
@@ -264,10 +268,17 @@ class _Base:
         self.seed = seed
         self.tuned_gemms = use_recorded_gemm_solutions() if self.device.type == "cuda" else False
 
-    def load_local(self, path: str) -> "._Base":
-        """Load weights from a LOCAL safetensors file with HuggingFace BERT names (never by model name)."""
+    def load_local(self, path: str, keep_gelu: bool = False) -> "._Base":
+        """Load weights from a LOCAL safetensors file with HuggingFace BERT names (never by model name).  BERT / MiniLM
+        checkpoints were trained with the exact (erf) GELU — what the reference's `CrossEncoder.predict` computes
+        (retrieval.py:675-678) — so loading real weights switches the model to `gelu="erf"`; keep_gelu=True keeps
+        whatever the config says (the faster tanh form, ~1e-3 of a logit away)."""
         from safetensors.torch import load_file
         sd = load_file(path)
+        if not keep_gelu:
+            self.config.gelu = "erf"
+            for layer in self.module.encoder.layers:
+                layer.gelu = "erf"
         own = self.module.state_dict()
         mapped = {}
         pre = "bert." if any(k.startswith("bert.") for k in sd) else ""

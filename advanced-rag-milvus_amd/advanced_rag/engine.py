@@ -244,7 +244,7 @@ class HybridSearchEngine:
             b["scores"][m, :, :cfg.top_k].copy_(b["dom_scores"])
 
     # ------------------------------------------------------------------ one batch
-    def search(self, q, sparse=None, domain_q=None, rowmask=None) -> dict:
+    def search(self, q, sparse=None, domain_q=None, rowmask=None, weights=None) -> dict:
         """q: float32 [B, dim] device tensor.  sparse: (indptr int64[B+1], idx int32, val float32, max_nnz)
         device tensors from `upload_sparse`.  domain_q: float32 [B, domain_dim] device tensor for the optional
         domain shard (engine built with domain_handle).  rowmask: packed uint8 device tensor (a filter expression's
@@ -252,7 +252,7 @@ class HybridSearchEngine:
         returns the buffer dict (fused_* and rr_* tensors are the results; they are reused by the next call)."""
         if self.stream is not None and self.torch.cuda.current_stream(self.device) != self.stream:
             with self.torch.cuda.stream(self.stream):
-                return self.search(q, sparse, domain_q, rowmask)
+                return self.search(q, sparse, domain_q, rowmask, weights)
         if domain_q is not None and self.hd is None:
             raise ValueError("domain queries need an engine built with domain_handle")
         t, cfg = self.torch, self.cfg
@@ -271,6 +271,9 @@ class HybridSearchEngine:
             self.h.search_dense_dev(q.data_ptr(), B, kp, b["ids"][0].data_ptr(), b["scores"][0].data_ptr(),
                                     b["flags"][0].data_ptr(), d_mask, stream)
         self._search_domain(b, domain_q, B, stream)
+        if weights is not None and (weights.dtype != t.float64 or tuple(weights.shape) != (B, 3) or not weights.is_contiguous()):
+            raise ValueError("weights must be a contiguous float64 [B, 3] device tensor")
+        b["w_query"] = weights          # kept alive until the next call reuses the buffer set
         return self._post_lists(b, B, stream)
 
     def _post_args(self, b: dict, B: int, n_lists: int, gathered) -> "nat.PostArgs":
@@ -336,7 +339,10 @@ class HybridSearchEngine:
             b["agg_flags"] = b["agg_flags_buf"]
         else:
             b["agg_flags"] = b["flags"]
-        nat.post_lists_dev(self._post_args(b, B, self.n_lists, g), B, stream)
+        a = self._post_args(b, B, self.n_lists, g)
+        wq = b.get("w_query")
+        a.w_query = wq.data_ptr() if wq is not None else None
+        nat.post_lists_dev(a, B, stream)
         b["list_ids"], b["list_scores"] = ids, scores
         return b
 

@@ -730,7 +730,7 @@ class MilvusIndexManager:
         if not len(payload[0]):
             return None
         w = list(weights) + [0.0] * (2 - len(weights))
-        fut = front.submit("hybrid", (int(top_k), filters, drop, float(w[0]), float(w[1]), int(rrf_k)), (dense_embedding, payload))
+        fut = front.submit("hybrid", (int(top_k), filters, drop, int(rrf_k)), (dense_embedding, payload, float(w[0]), float(w[1])))
         try:
             # no timer of its own: the caller (HybridRetriever.retrieve) already bounds the whole request with
             # RetrievalConstants.TIMEOUT_SECONDS, and a wait_for here is a task + a timer handle per request on the event

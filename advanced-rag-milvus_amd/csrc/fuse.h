@@ -360,8 +360,14 @@ __global__ __launch_bounds__(256) void post_lists_kernel(PostArgs pa) {
             __syncthreads();  // the merged list is read back below; the LDS staging is reused by the next modality
         }
     }
+    double w0 = a.w[0], w1 = a.w[1], w2 = a.w[2];
+    if (a.w_query) {  // per-request weights (a weight_adapter's): the same arithmetic, other operands
+        w0 = a.w_query[3 * (int64_t)q];
+        w1 = a.w_query[3 * (int64_t)q + 1];
+        w2 = a.w_query[3 * (int64_t)q + 2];
+    }
     rrf_fuse_block(q, fuse_ids[0], a.k_fuse[0], fuse_ids[1], a.k_in[1] ? a.k_fuse[1] : 0, fuse_ids[2],
-                   a.k_in[2] ? a.k_fuse[2] : 0, a.w[0], a.w[1], a.w[2], a.rrf_k, a.top_k, a.fused_ids, a.fused_scores,
+                   a.k_in[2] ? a.k_fuse[2] : 0, w0, w1, w2, a.rrf_k, a.top_k, a.fused_ids, a.fused_scores,
                    a.fused_methods, a.fused_n);
     if (!a.rerank) return;
     __syncthreads();

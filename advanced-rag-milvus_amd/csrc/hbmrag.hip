@@ -1125,7 +1125,7 @@ int build_sparse(hr_index* h) {
 // =============================================================================
 extern "C" {
 
-int hr_version(void) { return 10300; }  // 1.3.0: round 3 (fused finishing + post kernels, device filters, attention, masked streams)
+int hr_version(void) { return 10400; }  // 1.4.0: round 4 (per-query fusion weights, encoder layer kernels, head-dim-64 attention)
 
 const char* hr_last_error(const hr_index* h) {
     if (!h) return g_last_error.c_str();

@@ -277,6 +277,9 @@ typedef struct hr_post_args {
     int32_t n_flag_rows;
     int32_t reserved2;
     int32_t* agg_flags;
+    /* optional: fusion weights per query, [B][3] doubles (semantic, sparse, domain) — the reference lets a
+     * weight_adapter choose them per request (retrieval.py:251-262); NULL = `w` for every query of the batch */
+    const double* w_query;
 } hr_post_args;
 HR_API int hr_post_lists_dev(const hr_post_args* args, int B, void* stream);
 

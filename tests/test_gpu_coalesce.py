@@ -243,3 +243,102 @@ def test_a_bad_request_fails_alone(gpu, long_timeout):
         assert all([h["id"] for h in o] == [h["id"] for h in outs[0]] for o in outs[:-1])
     finally:
         asyncio.run(mgr.close())
+
+
+def test_cancelled_and_timed_out_callers_do_not_hurt_their_batch_mates(gpu, long_timeout):
+    """Callers that go away — cancelled tasks, a wait_for that expires — leave cancelled Futures in a round; the others
+    of the same launch must still get their (correct) hits and the worker must survive (set_result on a
+    cancelled Future raised InvalidStateError into the whole chunk)."""
+    rng = np.random.default_rng(9)
+    n, d, V, nq = 20000, 64, 400, 48
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    idx = np.sort(np.argpartition(rng.random((n, V)), 9, axis=1)[:, :10], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * 10)).astype(np.float32)
+    mgr = MilvusIndexManager(semantic_dim=d, sparse_dim=V, dtype="float16", enable_domain=False)
+    mgr.add_rows(X, (np.arange(n + 1, dtype=np.int64) * 10, idx, val))
+    mgr.finalize()
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    SQ = [{"indices": np.sort(rng.choice(V, 8, replace=False)).tolist(), "values": np.abs(rng.standard_normal(8)).tolist()}
+          for _ in range(nq)]
+
+    async def sequential():
+        return [await mgr.hybrid_search(Q[i], SQ[i], 10, None, (0.7, 0.3)) for i in range(nq)]
+
+    async def with_dropouts():
+        tasks = [asyncio.ensure_future(mgr.hybrid_search(Q[i], SQ[i], 10, None, (0.7, 0.3))) for i in range(nq)]
+        dense = [asyncio.ensure_future(mgr.search(Q[i], "semantic_index", 10)) for i in range(nq)]
+        await asyncio.sleep(0)                      # every task has submitted its request
+        for i in range(0, nq, 5):
+            tasks[i].cancel()
+            dense[i].cancel()
+        outs = await asyncio.gather(*tasks, *dense, return_exceptions=True)
+        # a second wave whose callers give up after 0 s: wait_for cancels the wrapped Future while the round runs
+        gone = await asyncio.gather(*[asyncio.wait_for(mgr.hybrid_search(Q[i], SQ[i], 10, None, (0.7, 0.3)), timeout=0)
+                                      for i in range(8)], return_exceptions=True)
+        after = await asyncio.gather(*[mgr.hybrid_search(Q[i], SQ[i], 10, None, (0.7, 0.3)) for i in range(nq)])
+        return outs[:nq], outs[nq:], gone, after
+
+    def ids(res):
+        return [(h["id"], float(s).hex(), m) for h, s, m in res]
+
+    try:
+        ref = [ids(r) for r in asyncio.run(sequential())]
+        hy, de, gone, after = asyncio.run(with_dropouts())
+        for i in range(nq):
+            if i % 5 == 0:
+                assert isinstance(hy[i], asyncio.CancelledError) and isinstance(de[i], asyncio.CancelledError)
+            else:
+                assert ids(hy[i]) == ref[i], i
+                assert isinstance(de[i], list) and len(de[i]) == 10
+        assert all(isinstance(g, (asyncio.TimeoutError, list)) for g in gone)
+        assert [ids(r) for r in after] == ref          # the worker is alive and still right
+        assert mgr._front.stats.get("worker_failures", 0) == 0
+        assert mgr._front._thread.is_alive()
+    finally:
+        asyncio.run(mgr.close())
+
+
+def test_requests_with_different_fusion_weights_share_one_round(gpu, long_timeout):
+    """A weight_adapter picks the fusion weights per request (reference retrieval.py:251-262): they are an operand of the
+    post kernel ([B, 3] doubles), not part of the batch key — 32 concurrent requests with 32 different weight pairs run
+    as one launch and return what each returns alone, fused scores bit for bit."""
+    rng = np.random.default_rng(21)
+    n, d, V, nq = 20000, 64, 400, 32
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    idx = np.sort(np.argpartition(rng.random((n, V)), 9, axis=1)[:, :10], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * 10)).astype(np.float32)
+    mgr = MilvusIndexManager(semantic_dim=d, sparse_dim=V, dtype="float32", enable_domain=False)
+    mgr.add_rows(X, (np.arange(n + 1, dtype=np.int64) * 10, idx, val))
+    mgr.finalize()
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    SQ = [{"indices": np.sort(rng.choice(V, 8, replace=False)).tolist(), "values": np.abs(rng.standard_normal(8)).tolist()}
+          for _ in range(nq)]
+    W = [(0.5 + 0.01 * i, 0.5 - 0.013 * i) for i in range(nq)]
+
+    async def alone():
+        return [await mgr.hybrid_search(Q[i], SQ[i], 10, None, W[i]) for i in range(nq)]
+
+    async def together():
+        return await asyncio.gather(*[mgr.hybrid_search(Q[i], SQ[i], 10, None, W[i]) for i in range(nq)])
+
+    try:
+        a = asyncio.run(alone())
+        st0 = dict(mgr._front.stats)
+        b = asyncio.run(together())
+        st = mgr._front.stats
+        assert st["hybrid_launches"] - st0["hybrid_launches"] <= 4, (st0, st)     # not one launch per weight pair
+        assert len(mgr._front._engines) == 1
+        for x, y in zip(a, b):
+            assert [(h["id"], float(s).hex(), m) for h, s, m in x] == [(h["id"], float(s).hex(), m) for h, s, m in y]
+        # and the weights matter: the host fusion with each request's own weights gives the same fused scores
+        for i in (0, 7, 31):
+            dl = asyncio.run(mgr.search(Q[i], "semantic_index", 20))
+            sl = asyncio.run(mgr.search(SQ[i], "sparse_index", 20))
+            fused = {}
+            for lst, w in ((dl, W[i][0]), (sl, W[i][1])):
+                for rank, h in enumerate(lst, 1):
+                    fused[h["id"]] = fused.get(h["id"], 0.0) + (1.0 / (60 + rank)) * w
+            top = sorted(fused.items(), key=lambda kv: -kv[1])[:10]
+            assert [float(s) for _, s, _ in b[i]] == [v for _, v in top]
+    finally:
+        asyncio.run(mgr.close())
