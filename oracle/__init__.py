@@ -197,6 +197,38 @@ def rrf_py(ids_a, ids_b, ids_c=(), wa: float = 0.7, wb: float = 0.3, wc: float =
             np.array([v[1] for _, v in items], dtype=np.int32))
 
 
+def mmr(ids, scores, contents, k: int, mmr_lambda: float):
+    """Greedy MMR of reference retrieval.py:493-516 (`_mmr_diversify`) on a fused list given as parallel sequences:
+    relevance = the fused score, similarity = token Jaccard of the lower-cased, whitespace-split contents (None = ""),
+    value = lambda*rel - (1-lambda)*max similarity to the selected; the FIRST candidate (in fused order) with a strictly
+    larger value wins; stops at k.  -> positions into the input, in selection order.  Pure Python: lists are <= 3k'."""
+    toks = [set((c or "").lower().split()) for c in contents]
+    cand = list(range(len(ids)))
+    sel = []
+    while cand and len(sel) < k:
+        best, best_val = None, -1e9
+        for i in cand:
+            if not sel:
+                val = scores[i]
+            else:
+                sim = max((len(toks[i] & toks[j]) / (len(toks[i] | toks[j]) or 1)) for j in sel)
+                val = mmr_lambda * scores[i] - (1 - mmr_lambda) * sim
+            if val > best_val:
+                best, best_val = i, val
+        sel.append(best)
+        cand.remove(best)
+    return sel
+
+
+def learned_rank(scores, method_counts, k: int, base_weight: float = 1.0, method_bonus: float = 0.1):
+    """The deterministic rerank branch of the reference (retrieval.py:544-563 with ranker.py:109-125, default
+    LearnedRankerConfig, recency_weight = 0): new = base_weight*score + method_bonus*len(methods), float64, evaluated left
+    to right as Python does; stable descending sort; cut to k.  -> (positions, new scores)."""
+    new = [float(base_weight * float(s) + method_bonus * float(m) + 0.0 * 0.0) for s, m in zip(scores, method_counts)]
+    order = sorted(range(len(new)), key=lambda i: new[i], reverse=True)[:k]
+    return order, [new[i] for i in order]
+
+
 def float_to_half_bits(x: np.ndarray) -> np.ndarray:
     """fp32 -> fp16 bit patterns via the C routine (cross-check of numpy's astype)."""
     flat = np.ascontiguousarray(x, dtype=np.float32).ravel()

@@ -224,3 +224,112 @@ def test_g6_search_results_have_the_references_shape_on_device(gpu):
             assert str(ei.value) == e["message"]
     finally:
         asyncio.run(mgr.close())
+
+
+# --------------------------------------------------------------------------- G11 / G12 (round 4)
+def _mmr_manager(dtype, X, sparse_csr, with_sparse, **kw):
+    """Config 1 with the contents and scalar fields of the G11 / G12 fixtures (g5_data.mmr_content / payload_row)."""
+    N, D = X.shape
+    mgr = MilvusIndexManager(semantic_dim=D, sparse_dim=g5_data.SPARSE_DIM, dtype=dtype, enable_domain=False, **kw)
+    if not with_sparse:
+        del mgr.collections["sparse_index"]
+    _fill_g12_rows(mgr, X, sparse_csr if with_sparse else None)
+    return mgr
+
+
+def _fill_g12_rows(mgr, X, sparse_csr):
+    rows = [g5_data.payload_row(r) for r in range(X.shape[0])]
+    cols = {k: [row[k] for row in rows] for k in ("doc_id", "chunk_index", "token_count", "entropy", "redundancy",
+                                                   "domain_density", "timestamp", "metadata_json")}
+    mgr.add_rows(X, sparse_csr, ids=[row["chunk_id"] for row in rows], contents=[row["content"] for row in rows], **cols)
+    mgr.finalize()
+
+
+class _KeyedGen:
+    """Embeddings keyed by the trailing query number of the text ("... q<i>"), as in gen_golden_g11_g12.py."""
+
+    def __init__(self, Q, SQ, fixed=None):
+        self.Q, self.SQ, self.fixed = Q, SQ, fixed
+
+    def _i(self, text):
+        return self.fixed if self.fixed is not None else int(text.rsplit("q", 1)[1])
+
+    def encode_semantic(self, text):
+        return self.Q[self._i(text)]
+
+    def encode_sparse(self, text):
+        qi, qv = self.SQ[self._i(text)]
+        return {"indices": qi.tolist(), "values": qv.astype(float).tolist()}
+
+    def encode_domain(self, text, domain=None):
+        return np.zeros(8, np.float32)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_g11_retrieve_under_mmr_profiles_on_device_matches_reference(gpu, long_timeout, dtype):
+    """G11b on the device: the reference's HybridRetriever.retrieve under profile_hint = troubleshooting / analysis /
+    summary (k' = 60 / 60 / 80; MMR at lambda 0.5 / 0.8 / off, reference retrieval.py:142-213, :488-516) — ids in order,
+    float64 fused scores bit for bit, method tags, profile; the MMR profiles take the general path of the front (the
+    whole fused list is needed), `summary` the one-round path."""
+    from advanced_rag.embedding_cache import initialize_caches
+    g, X, csr, Q, SQ = g5_data.inputs()
+    runs = gold("g11_mmr.json")["retrieve"]
+    for with_sparse in (True, False):
+        mgr = _mmr_manager(dtype, X, csr, with_sparse)
+        try:
+            for run in (r for r in runs if r["with_sparse"] == with_sparse):
+                initialize_caches()
+                mgr.embedding_generator = _KeyedGen(Q, SQ, fixed=run["query"])
+                retr = HybridRetriever(mgr, RetrievalConfig(top_k=20))
+                out = asyncio.run(retr.retrieve("plain statement", profile_hint=run["profile_hint"]))
+                assert [o["id"] for o in out] == run["ids"], (with_sparse, run["profile_hint"], run["query"])
+                assert [float(o["score"]).hex() for o in out] == run["scores"]
+                assert [sorted(o["retrieval_methods"]) for o in out] == run["methods"]
+                assert out[0]["metadata"]["retrieval_profile"] == run["profile"]
+                assert (retr.config.enable_mmr, retr.config.mmr_lambda, retr.config.top_k) == (run["enable_mmr"], run["mmr_lambda"], run["top_k"])
+        finally:
+            asyncio.run(mgr.close())
+
+
+def test_g12_pipeline_retrieve_on_device_matches_reference(gpu, long_timeout):
+    """G12 on the device: this package's AdvancedRAGPipeline.retrieve() with the learned ranker on, over an in-HBM shard
+    holding config 1, returns what the REFERENCE's AdvancedRAGPipeline(connect_to_milvus=False).retrieve() returned over
+    fake Milvus collections with the same rows (reference pipeline.py:217-309): chunk_id order, float64 scores bit for
+    bit, retrieval_method, contents, metadata keys and values, the RetrievalResult fields, and the rerank_top_k quirk."""
+    from advanced_rag import AdvancedRAGPipeline, PipelineConfig
+    from advanced_rag.embedding_cache import initialize_caches
+    g, X, csr, Q, SQ = g5_data.inputs()
+    cases = gold("g12_pipeline.json")["cases"]
+    for c in cases:
+        initialize_caches()
+        pipe = AdvancedRAGPipeline(connect_to_milvus=False,
+                                   config=PipelineConfig(enable_audit_logging=False, rerank_top_k=c["pipeline_rerank_top_k"],
+                                                         enable_reranking=c["enable_reranking"], top_k=c["top_k"]),
+                                   semantic_dim=X.shape[1], sparse_dim=g5_data.SPARSE_DIM, dtype="float32", enable_domain=False)
+        mgr = pipe.index_manager
+        try:
+            if not c["with_sparse"]:
+                del mgr.collections["sparse_index"]
+            _fill_g12_rows(mgr, X, csr if c["with_sparse"] else None)
+            mgr.embedding_generator = _KeyedGen(Q, SQ)
+            pipe.retriever.config.enable_learned_ranker = True
+            assert pipe.retriever.config.rerank_top_k == c["retriever_rerank_top_k"]      # never forwarded (quirk kept)
+            results, metrics = asyncio.run(pipe.retrieve(c["query"], context=c["context"]))
+            assert len(results) == c["n"], c["label"]
+            assert [r.chunk_id for r in results] == c["chunk_ids"], c["label"]
+            assert [float(r.score).hex() for r in results] == c["scores"], c["label"]
+            assert [r.retrieval_method for r in results] == c["retrieval_methods"]
+            assert [r.content for r in results] == c["contents"]
+            assert [r.metadata["doc_id"] for r in results] == c["doc_ids"]
+            assert [r.metadata["chunk_index"] for r in results] == c["chunk_indexes"]
+            assert [r.metadata.get("retrieval_profile") for r in results] == c["profiles"]
+            assert sorted(k for k in results[0].metadata if k != "recency") == c["metadata_keys"]
+            assert sorted(results[0].__dataclass_fields__) == c["result_fields"]
+            assert [r.audit_trail for r in results] == c["audit_trails"]
+            assert type(metrics).__name__ == c["metrics_type"]
+            for r in results:       # FLOAT fields come back as the float32 value, as pymilvus hands them over
+                row = g5_data.payload_row(int(r.chunk_id.rsplit("::", 1)[1], 16))
+                assert (r.metadata["entropy"], r.metadata["redundancy"], r.metadata["domain_density"], r.metadata["timestamp"]) == \
+                       (row["entropy"], row["redundancy"], row["domain_density"], row["timestamp"])
+        finally:
+            asyncio.run(pipe.close())

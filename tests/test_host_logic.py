@@ -563,3 +563,71 @@ def test_payload_columns_are_append_only_arrays_not_python_objects():
     assert s.compare_rows(np.array([4, 5]), "<", "0123456789abcdefB").tolist() == [False, True]
     s.append("tail")
     assert s.keys().shape == (len(vals) + 1, 2) and StringColumn.key_of("tail") == (int(s.keys()[-1, 0]), int(s.keys()[-1, 1]))
+
+
+# --------------------------------------------------------------------------- G11 / G12 (round 4): MMR, profiles, pipeline
+def test_fuse_results_with_mmr_matches_reference_g11():
+    """`_fuse_results` with enable_mmr=True (reference retrieval.py:488-516) at lambda 0.5 / 0.7 / 0.8 / 0 / 1: this
+    package's host fusion + `_mmr_diversify` return the imported reference's order, float64 scores and method tags."""
+    cases = gold("g11_mmr.json")["fuse"]
+    for c in cases:
+        hit = lambda i, r: {"id": i, "content": c["content"][i], "score": 1.0 - 0.01 * r}   # noqa: E731
+        r = HybridRetriever(index_manager=None, config=RetrievalConfig(dense_weight=c["dense_weight"], sparse_weight=c["sparse_weight"],
+                                                                       top_k=c["top_k"], enable_mmr=True, mmr_lambda=c["mmr_lambda"]))
+        out = r._fuse_results([hit(i, n) for n, i in enumerate(c["semantic"])], [hit(i, n) for n, i in enumerate(c["sparse"])],
+                              [hit(i, n) for n, i in enumerate(c["domain"])])
+        assert [o["id"] for o in out] == c["ids"], c["label"]
+        assert [float(o["score"]).hex() for o in out] == c["scores"], c["label"]
+        assert [sorted(o["retrieval_methods"]) for o in out] == c["methods"], c["label"]
+
+
+def test_retrieve_under_mmr_profiles_matches_reference_g11():
+    import g5_data
+    g, X, csr, Q, SQ = g5_data.inputs()
+    old = RetrievalConstants.TIMEOUT_SECONDS
+    RetrievalConstants.TIMEOUT_SECONDS = 60.0
+    try:
+        for run in gold("g11_mmr.json")["retrieve"]:
+            mgr = g5_data.NumpyFlatManager(X, csr, Q, SQ, run["with_sparse"], fixed_query=run["query"])
+            retr = HybridRetriever(mgr, RetrievalConfig(top_k=20))
+            out = asyncio.run(retr.retrieve("plain statement", profile_hint=run["profile_hint"]))
+            assert sorted(set(mgr.seen_top_k)) == run["search_top_k"]
+            assert [o["id"] for o in out] == run["ids"], (run["profile_hint"], run["query"])
+            assert [float(o["score"]).hex() for o in out] == run["scores"]
+            assert [sorted(o["retrieval_methods"]) for o in out] == run["methods"]
+            assert out[0]["metadata"]["retrieval_profile"] == run["profile"]
+    finally:
+        RetrievalConstants.TIMEOUT_SECONDS = old
+
+
+def test_pipeline_retrieve_matches_reference_g12():
+    """AdvancedRAGPipeline.retrieve() on its deterministic branch (learned ranker) against what the REFERENCE's pipeline
+    returned over fake collections with the same rows (reference pipeline.py:217-309): order, scores, retrieval_method,
+    metadata, the number of results for PipelineConfig.rerank_top_k = 5 / 7 / 12, reranking disabled, top_k = 10."""
+    import g5_data
+    g, X, csr, Q, SQ = g5_data.inputs()
+    old = RetrievalConstants.TIMEOUT_SECONDS
+    RetrievalConstants.TIMEOUT_SECONDS = 60.0
+    try:
+        for c in gold("g12_pipeline.json")["cases"]:
+            p = AdvancedRAGPipeline(connect_to_milvus=False,
+                                    config=PipelineConfig(enable_audit_logging=False, rerank_top_k=c["pipeline_rerank_top_k"],
+                                                          enable_reranking=c["enable_reranking"], top_k=c["top_k"]))
+            p.index_manager = g5_data.NumpyFlatManager(X, csr, Q, SQ, c["with_sparse"])
+            p.retriever.index_manager = p.index_manager
+            p.retriever.config.enable_learned_ranker = True
+            assert p.retriever.config.rerank_top_k == c["retriever_rerank_top_k"]
+            results, metrics = asyncio.run(p.retrieve(c["query"], context=c["context"]))
+            assert sorted(set(p.index_manager.seen_top_k)) == c["search_limits"]
+            assert len(results) == c["n"], c["label"]
+            assert [r.chunk_id for r in results] == c["chunk_ids"], c["label"]
+            assert [float(r.score).hex() for r in results] == c["scores"], c["label"]
+            assert [r.retrieval_method for r in results] == c["retrieval_methods"]
+            assert [r.content for r in results] == c["contents"]
+            assert [r.metadata["doc_id"] for r in results] == c["doc_ids"]
+            assert [r.metadata.get("retrieval_profile") for r in results] == c["profiles"]
+            assert sorted(k for k in results[0].metadata if k != "recency") == c["metadata_keys"]
+            assert sorted(results[0].__dataclass_fields__) == c["result_fields"]
+            assert type(metrics).__name__ == c["metrics_type"]
+    finally:
+        RetrievalConstants.TIMEOUT_SECONDS = old

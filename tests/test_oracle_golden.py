@@ -133,3 +133,87 @@ def test_oracle_search_chain_reproduces_the_references_retrieve_on_config1():
         assert [g5_data.row_id(int(r)) for r in ids] == run["ids"], (run["with_sparse"], q)
         assert [float(s).hex() for s in scores] == run["scores"]
         assert [sorted(n for bit, n in enumerate(names) if (int(m) >> bit) & 1) for m in methods] == run["methods"]
+
+
+# --------------------------------------------------------------------------- G11 / G12 (round 4)
+NAMES3 = ("semantic", "sparse", "domain")
+
+
+def _names(mask):
+    return sorted(n for bit, n in enumerate(NAMES3) if (int(mask) >> bit) & 1)
+
+
+def test_oracle_mmr_matches_reference_fuse_results_with_mmr():
+    """G11a: `_fuse_results` of the imported reference with enable_mmr=True (retrieval.py:488-516) at lambda 0.5 / 0.7 /
+    0.8 (+ 0 and 1, empty contents, lists shorter than top_k, a domain list): oracle.rrf -> oracle.mmr gives the same
+    order, the same float64 fused scores and method tags."""
+    cases = gold("g11_mmr.json")["fuse"]
+    assert len(cases) >= 15 and {c["mmr_lambda"] for c in cases} >= {0.5, 0.7, 0.8}
+    for c in cases:
+        (a, b, d), back = _intern(c["semantic"], c["sparse"], c["domain"])
+        ids, scores, methods = oracle.rrf(a, b, d, c["dense_weight"], c["sparse_weight"], 0.2, 60)
+        names = [back[int(i)] for i in ids]
+        sel = oracle.mmr(names, [float(s) for s in scores], [c["content"][n] for n in names], c["top_k"], c["mmr_lambda"])
+        assert [names[i] for i in sel] == c["ids"], c["label"]
+        assert [float(scores[i]).hex() for i in sel] == c["scores"], c["label"]
+        assert [_names(methods[i]) for i in sel] == c["methods"], c["label"]
+
+
+def _oracle_fused(X, ptr, idx, val, Q, SQ, q, kp, with_sparse, wa=0.7, wb=0.3):
+    di, _ = oracle.dense_search(X, Q[q:q + 1], kp, oracle.COSINE)
+    if with_sparse:
+        si, _ = oracle.sparse_search(ptr, idx, val, [SQ[q]], kp, 0.2)
+        sl = si[0][si[0] >= 0]
+    else:
+        sl = ()
+    return di[0], sl, oracle.rrf(di[0], sl, (), wa, wb, 0.2, 60)
+
+
+def test_oracle_chain_reproduces_the_references_retrieve_under_the_mmr_profiles():
+    """G11b: the reference's HybridRetriever.retrieve on config 1 with profile_hint = troubleshooting / analysis /
+    summary (top_k 30 / 30 / 40, searches with k' = 60 / 60 / 80, MMR at 0.5 / 0.8 / off)."""
+    import g5_data
+    g, X, (ptr, idx, val), Q, SQ = g5_data.inputs()
+    runs = gold("g11_mmr.json")["retrieve"]
+    assert len(runs) == 30 and {r["profile_hint"] for r in runs} == {"troubleshooting", "analysis", "summary"}
+    for run in runs:
+        top_k = run["top_k"]
+        assert run["search_top_k"] == [2 * top_k] and run["profile"] == run["profile_hint"]
+        _, _, (ids, scores, methods) = _oracle_fused(X, ptr, idx, val, Q, SQ, run["query"], 2 * top_k, run["with_sparse"])
+        if run["enable_mmr"]:
+            sel = oracle.mmr(ids, [float(s) for s in scores], [g5_data.mmr_content(int(r)) for r in ids], top_k, run["mmr_lambda"])
+        else:
+            sel = list(range(len(ids)))
+        sel = sel[:top_k]
+        assert [g5_data.row_id(int(ids[i])) for i in sel] == run["ids"], (run["profile_hint"], run["query"])
+        assert [float(scores[i]).hex() for i in sel] == run["scores"]
+        assert [_names(methods[i]) for i in sel] == run["methods"]
+
+
+def test_oracle_chain_reproduces_the_references_pipeline_retrieve():
+    """G12: the reference's AdvancedRAGPipeline(connect_to_milvus=False).retrieve() with the learned ranker switched on
+    (pipeline.py:217-309, retrieval.py:544-563, ranker.py:109-125) over fake collections holding config 1: chunk ids in
+    order, float64 scores bit for bit, the payload's method tag, and how many come back for PipelineConfig.rerank_top_k =
+    5 / 7 / 12 (the retriever's own rerank_top_k stays 5 and is never consulted)."""
+    import g5_data
+    g, X, (ptr, idx, val), Q, SQ = g5_data.inputs()
+    cases = gold("g12_pipeline.json")["cases"]
+    assert len(cases) >= 15
+    for c in cases:
+        q = int(c["query"].rsplit("q", 1)[1])
+        top_k = c["top_k"]
+        assert c["search_limits"] == [2 * top_k] and c["retriever_rerank_top_k"] == 5
+        dl, sl, (ids, scores, methods) = _oracle_fused(X, ptr, idx, val, Q, SQ, q, 2 * top_k, c["with_sparse"])
+        ids, scores, methods = ids[:top_k], scores[:top_k], methods[:top_k]
+        if c["enable_reranking"]:
+            order, new = oracle.learned_rank(scores, [bin(int(m)).count("1") for m in methods], c["pipeline_rerank_top_k"])
+        else:
+            order = list(range(min(len(ids), c["pipeline_rerank_top_k"])))
+            new = [float(scores[i]) for i in order]
+        assert c["n"] == len(order) == min(c["pipeline_rerank_top_k"], len(ids))
+        assert [g5_data.row_id(int(ids[i])) for i in order] == c["chunk_ids"], c["label"]
+        assert [float(s).hex() for s in new] == c["scores"], c["label"]
+        dense_set = set(int(r) for r in dl)
+        assert ["semantic" if int(ids[i]) in dense_set else "sparse" for i in order] == c["retrieval_methods"]
+        assert c["contents"] == [g5_data.mmr_content(int(ids[i])) for i in order]
+        assert c["profiles"] == ["default"] * len(order)
