@@ -109,6 +109,12 @@ _SIGNATURES = {
     "hr_attention_rows_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int64,
                                              _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_float,
                                              _c.c_void_p]),
+    "hr_linear_rows_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int,
+                                          _c.c_int64, _c.c_void_p]),
+    "hr_attention_fr_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_float, _c.c_void_p]),
+    "hr_encoder_tail_f16_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p,
+                                           _c.c_int64, _c.c_int, _c.c_int, _c.c_float, _c.c_int, _c.c_void_p]),
     "hr_set_profiling": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "hr_last_kernel_ms": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int]),
 }
@@ -526,6 +532,38 @@ def attention_f16_dev(d_qkv: int, d_lengths: int, d_out: int, n_seq: int, T: int
     L = load_library()
     rc = L.hr_attention_f16_dev(_vp(d_qkv), _vp(d_lengths) if d_lengths else None, _vp(d_out), n_seq, T, heads, head_dim,
                                 float(scale), _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def linear_rows_f16_dev(d_x: int, x_fr: bool, d_w_packed: int, d_bias: int, d_out: int, rows: int, K: int, N: int, out_stride: int,
+                        stream: int = 0):
+    """out[r][:N] = x[r][:K] W^T + bias through the hand-written MFMA kernel (x row-major with naturally packed weights, or
+    in fragment order with weights in accumulator k order: encoder_kernels.pack_natural / pack_accumulator_order)."""
+    L = load_library()
+    rc = L.hr_linear_rows_f16_dev(_vp(d_x), 1 if x_fr else 0, _vp(d_w_packed), _vp(d_bias), _vp(d_out), rows, K, N, out_stride,
+                                  _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def attention_fr_f16_dev(d_qkv: int, d_lengths: int, d_out_fr: int, n_seq: int, T: int, heads: int, head_dim: int, scale: float,
+                         stream: int = 0):
+    """hr_attention_f16_dev with its output in fragment order (what hr_encoder_tail_f16_dev reads)."""
+    L = load_library()
+    rc = L.hr_attention_fr_f16_dev(_vp(d_qkv), _vp(d_lengths) if d_lengths else None, _vp(d_out_fr), n_seq, T, heads, head_dim,
+                                   float(scale), _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def encoder_tail_f16_dev(d_attn_fr: int, d_x: int, x_fr: bool, d_out: int, out_fr: bool, d_wstream: int, d_tables: int, rows: int,
+                         hidden: int, intermediate: int, eps: float, gelu_erf: bool, stream: int = 0):
+    """Everything of a post-LN layer after the attention in one launch (csrc/encoder_layer.h)."""
+    L = load_library()
+    rc = L.hr_encoder_tail_f16_dev(_vp(d_attn_fr), _vp(d_x), 1 if x_fr else 0, _vp(d_out), 1 if out_fr else 0, _vp(d_wstream),
+                                   _vp(d_tables), rows, hidden, intermediate, float(eps), 1 if gelu_erf else 0,
+                                   _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
 

@@ -31,6 +31,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _native
+from .encoder_kernels import LayerKernels, encoder_tail, fr_rows, linear_rows
 
 _WORD = re.compile(r"\w+|[^\w\s]")
 PAD, CLS, SEP = 0, 101, 102
@@ -115,12 +116,42 @@ class _Layer(nn.Module):
         self.up = nn.Linear(c.hidden, c.intermediate)
         self.down = nn.Linear(c.intermediate, c.hidden)
         self.ln2 = nn.LayerNorm(c.hidden, eps=c.eps)
+        self.kernels = LayerKernels()     # packed operands of the hand-written layer kernels (built on first GPU use)
+        self.use_layer_kernels = True     # False: the PyTorch GEMMs + fused elementwise kernels of round 3 (A/B, tests)
+
+    def _hip_attention_ok(self, x, lengths, hd, T) -> bool:
+        return (lengths is not None and x.is_cuda and x.dtype == torch.float16 and
+                ((hd == 32 and T <= 1024) or (hd == 64 and T <= 512)))
+
+    def _fused_ok(self, x, lengths, hd, T) -> bool:
+        return (self.use_layer_kernels and self._hip_attention_ok(x, lengths, hd, T) and self.gelu in ("tanh", "erf")
+                and LayerKernels.supports(self))
+
+    def forward_fused(self, x2, B, T, lengths, x_fr: bool = False, out_fr: bool = False):
+        """The layer as three hand-written launches (csrc/encoder_layer.h, attention.h): QKV projection -> attention ->
+        output projection + residual + LayerNorm + FFN + residual + LayerNorm.  x2: [B * T, H] row-major, or the
+        fragment-order buffer of the previous layer (x_fr); returns row-major [B * T, H] or fragment order (out_fr).
+        Between the launches of a chain of layers the activations stay in fragment order."""
+        H = x2.shape[1]
+        hd = H // self.heads
+        M = B * T
+        k = self.kernels.ensure(self)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        qkv = linear_rows(x2, k.qkv_w_fr if x_fr else k.qkv_w, k.qkv_b, 3 * H, rows=M, x_fr=x_fr)
+        a = torch.empty((fr_rows(M), H), dtype=x2.dtype, device=x2.device)
+        _native.attention_fr_f16_dev(qkv.data_ptr(), lengths.data_ptr(), a.data_ptr(), B, T, self.heads, hd, hd ** -0.5,
+                                     torch.cuda.current_stream(x2.device).cuda_stream)
+        return encoder_tail(a, x2, k, self.up.weight.shape[0], float(self.ln1.eps), self.gelu == "erf", rows=M, x_fr=x_fr,
+                            out_fr=out_fr)
 
     def forward(self, x, attn_bias, lengths=None):
         B, T, H = x.shape
         hd = H // self.heads
+        if self._fused_ok(x, lengths, hd, T):
+            return self.forward_fused(x.reshape(B * T, H), B, T, lengths).view(B, T, H)
         qkv = self.qkv(x)
-        if lengths is not None and x.is_cuda and x.dtype == torch.float16 and hd == 32 and T <= 1024:
+        if self._hip_attention_ok(x, lengths, hd, T):
             # head dimension 32 on the GPU: the HIP attention kernel reads the fused projection as it stands and writes
             # the [tokens, hidden] layout the output projection wants — no permute / transpose copies, no SDPA
             qkv = qkv.contiguous()
@@ -143,9 +174,14 @@ class _Layer(nn.Module):
         B, T, H = x.shape
         hd = H // self.heads
         W, b = self.qkv.weight, self.qkv.bias
-        kv = F.linear(x, W[H:], b[H:])                                                  # [B, T, 2, heads, hd]
+        if self._fused_ok(x, lengths, hd, T):   # keys and values of every token through the hand-written projection
+            k = self.kernels.ensure(self)
+            x2 = x.reshape(B * T, H)
+            kv = linear_rows(x2 if x2.is_contiguous() else x2.contiguous(), k.kv_w, k.kv_b, 2 * H).view(B, T, 2 * H)
+        else:
+            kv = F.linear(x, W[H:], b[H:])                                              # [B, T, 2, heads, hd]
         q = F.linear(x[:, 0], W[:H], b[:H])                                             # [B, heads, hd]
-        if lengths is not None and x.is_cuda and x.dtype == torch.float16 and hd == 32 and T <= 1024:
+        if self._hip_attention_ok(x, lengths, hd, T):
             # the HIP attention kernel with ONE query row per sequence against the K / V buffer (hr_attention_rows_f16_dev)
             kv, q = kv.contiguous(), q.contiguous()
             a = torch.empty((B, 1, H), dtype=x.dtype, device=x.device)
@@ -202,8 +238,16 @@ class BertEncoder(nn.Module):
         # key mask is "position < length"
         lengths = mask.sum(dim=1).to(torch.int32) if x.is_cuda and x.dtype == torch.float16 else None
         n_full = len(self.layers) - (1 if first_token_only else 0)
-        for layer in self.layers[:n_full]:
-            x = layer(x, bias, lengths)
+        H = x.shape[-1]
+        if n_full and all(layer._fused_ok(x, lengths, H // layer.heads, T) for layer in self.layers[:n_full]):
+            # every layer through the hand-written kernels: the activations stay in fragment order between the layers
+            x2 = x.reshape(B * T, H)
+            for i, layer in enumerate(self.layers[:n_full]):
+                x2 = layer.forward_fused(x2, B, T, lengths, x_fr=i > 0, out_fr=i + 1 < n_full)
+            x = x2.view(B, T, H)
+        else:
+            for layer in self.layers[:n_full]:
+                x = layer(x, bias, lengths)
         if first_token_only:
             x = self.layers[-1].forward_first_token(x, mask, lengths)
         return x

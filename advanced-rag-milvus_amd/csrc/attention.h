@@ -1,6 +1,8 @@
-// Self-attention of the encoder / cross-encoder forward for head dimension 32 (MiniLM-L6-H384: 12 heads x 32 —
-// the model class the reference's CrossEncoderReranker names, retrieval.py:651-662), straight from the fused QKV
-// projection's output to the [tokens, hidden] layout the output projection reads.  PyTorch's SDPA spends 0.53 ms per
+// Self-attention of the encoder / cross-encoder forward for head dimensions 32 (MiniLM-L6-H384: 12 heads x 32 —
+// the model class the reference's CrossEncoderReranker names, retrieval.py:651-662) and 64 (bge-base 12 x 64, bge-large
+// 16 x 64: the sentence encoders BASELINE configs 3-5 name; round 4: template parameter HD, two k-steps per score tile and
+// four output dim tiles), straight from the fused QKV projection's output to the [tokens, hidden] layout the output
+// projection reads.  The text below describes HD = 32; HD = 64 differs only in those counts.  PyTorch's SDPA spends 0.53 ms per
 // layer on 2560 sequences x 128 tokens (15x its memory bound: a 32-wide head fills a quarter of a generic flash
 // tile), plus the permute / transpose copies around it.
 //
@@ -25,7 +27,8 @@
 namespace hbmrag {
 
 constexpr int kAttnHeadDim = 32;
-constexpr int kAttnMaxT = 1024;   // K + V of a (sequence, head) in LDS: 128 bytes per token
+constexpr int kAttnMaxT = 1024;   // K + V of a (sequence, head) in LDS: 4 * HD bytes per token (HD = 64: 512 tokens)
+constexpr int kAttnLdsBytes = kAttnMaxT * 128;
 
 __device__ inline float wave_col_max(float v) { return col4_max(v); }   // over the four lane groups that share a query column
 
@@ -49,49 +52,61 @@ struct AttnArgs {
     const int32_t* lengths;
     int64_t q_seq, q_tok, kv_seq, kv_tok;   // strides in halves
     int T, n_queries, heads, n_qblocks;     // keys per sequence; the first n_queries tokens are the queries
-    int64_t n_pairs;
+    int64_t n_pairs;                        // HD = 32: head pairs (two heads share a 128-byte line); HD = 64: heads
     float scale_log2e;
+    int out_fr;                             // out in fragment order (encoder_layer.h): what encoder_tail_kernel reads
 };
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kernel(AttnArgs a) {
+template <int NW, int HD>
+__global__ __launch_bounds__(64 * NW, (NW == 4 && HD == 32) ? 2 : 1) void attention_kernel(AttnArgs a) {
+    constexpr int KS = HD / 32;   // k-steps of a score tile
+    constexpr int DT = HD / 16;   // output dim tiles
+    constexpr int PC = HD / 8;    // 16-byte pieces of a key row
+    constexpr int HG = HD == 32 ? 2 : 1;   // heads whose blocks are kept on one XCD (they share 128-byte lines)
     const int32_t* __restrict__ lengths = a.lengths;
     _Float16* __restrict__ out = a.out;
     const int T = a.T, heads = a.heads, n_qblocks = a.n_qblocks;
     const int64_t n_pairs = a.n_pairs;
     const float scale_log2e = a.scale_log2e;
-    extern __shared__ half8_t attn_vt[];   // [chunks][2 dim tiles][64 lanes] fragments of V^T, then K: [chunks * 32 keys][4] pieces
-    const int G = 2 * n_qblocks;
+    extern __shared__ half8_t attn_vt[];   // [chunks][DT dim tiles][64 lanes] fragments of V^T, then K: [chunks * 32 keys][PC] pieces
+    const int G = HG * n_qblocks;
     const int64_t L = blockIdx.x;
-    const int64_t P = (L / (8 * G)) * 8 + (L & 7);        // head pair: sequence * ceil(heads / 2) + pair of the sequence
+    const int64_t P = (L / (8 * G)) * 8 + (L & 7);        // head group: sequence * ceil(heads / HG) + group of the sequence
     const int i_blk = (int)((L / 8) % G);
     if (P >= n_pairs) return;
-    const int pairs_per_seq = (heads + 1) / 2;
-    const int seq = (int)(P / pairs_per_seq), head = 2 * (int)(P % pairs_per_seq) + i_blk / n_qblocks;
+    const int pairs_per_seq = (heads + HG - 1) / HG;
+    const int seq = (int)(P / pairs_per_seq), head = HG * (int)(P % pairs_per_seq) + i_blk / n_qblocks;
     const int q_block = i_blk % n_qblocks;
     if (head >= heads) return;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int col = lane & 15, g = lane >> 4;
-    const int H = heads * kAttnHeadDim;
+    const int H = heads * HD;
     const int len = lengths ? min(lengths[seq], T) : T;
     const int n_chunks = (T + 31) / 32;
-    const _Float16* qb = a.q + seq * a.q_seq + head * kAttnHeadDim;
-    const _Float16* kb = a.k + seq * a.kv_seq + head * kAttnHeadDim;
-    const _Float16* vb = a.v + seq * a.kv_seq + head * kAttnHeadDim;
+    const _Float16* qb = a.q + seq * a.q_seq + head * HD;
+    const _Float16* kb = a.k + seq * a.kv_seq + head * HD;
+    const _Float16* vb = a.v + seq * a.kv_seq + head * HD;
     const int NQ = a.n_queries;
-    half8_t* ks = attn_vt + n_chunks * 2 * 64;
+    half8_t* ks = attn_vt + n_chunks * DT * 64;
+    // K rows in LDS: the PC pieces of a key are XOR-rotated so that the 16 lanes of one ds_read_b128 group (16 different
+    // keys, one piece each) hit 16 different 16-byte bank groups: rows of 64 bytes rotate by key / 4 over 4 slots, rows of
+    // 128 bytes by key / 2 over 8
+    auto rot = [](int key) { return HD == 32 ? ((key >> 2) & 3) : ((key >> 1) & 7); };
 
     // Q is requested before K and V are staged
     const int q0 = q_block * 32 * NW + wid * 32;
-    half8_t qf[2], kf[2];
-    auto load_k = [&](int c, half8_t (&kfr)[2]) {
+    half8_t qf[2][KS], kf[2][KS];
+    auto load_k = [&](int c, half8_t (&kfr)[2][KS]) {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) kfr[kt] = ks[(32 * c + 16 * kt + col) * 4 + (g ^ ((col >> 2) & 3))];
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) kfr[kt][s] = ks[(32 * c + 16 * kt + col) * PC + ((4 * s + g) ^ rot(col))];
     };
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = min(q0 + 16 * qt + col, NQ - 1);
-        qf[qt] = *reinterpret_cast<const half8_t*>(qb + (int64_t)q * a.q_tok + 8 * g);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) qf[qt][s] = *reinterpret_cast<const half8_t*>(qb + (int64_t)q * a.q_tok + 32 * s + 8 * g);
     }
     // the softmax scale (x log2 e) goes into Q once — 8 multiplies per query tile instead of one per score; the
     // product is rounded to fp16 like Q itself (|scale| < 1: no overflow), well inside the kernel's fp16 tolerance
@@ -99,37 +114,39 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) qf[qt][i] *= qs;
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qf[qt][s][i] *= qs;
 
     // ---- stage K (as it stands) and V^T: thread takes (key, 8 dims) pieces; dim d of V's key k goes to fragment
     // (chunk, d >> 4), lane (d & 15) + 16 g', slot j
     _Float16* vt = reinterpret_cast<_Float16*>(attn_vt);
-    for (int piece = threadIdx.x; piece < n_chunks * 32 * 4; piece += 64 * NW) {
-        const int key = piece >> 2, e = piece & 3;
+    for (int piece = threadIdx.x; piece < n_chunks * 32 * PC; piece += 64 * NW) {
+        const int key = piece / PC, e = piece % PC;
         half8_t v = {0, 0, 0, 0, 0, 0, 0, 0}, kk8 = {0, 0, 0, 0, 0, 0, 0, 0};
         if (key < T) {
             kk8 = *reinterpret_cast<const half8_t*>(kb + (int64_t)key * a.kv_tok + 8 * e);
             v = *reinterpret_cast<const half8_t*>(vb + (int64_t)key * a.kv_tok + 8 * e);
         }
-        ks[key * 4 + (e ^ ((key >> 2) & 3))] = kk8;   // pieces of a key rotated by key / 4: the 16 lanes of a fragment read hit 16 different bank groups
+        ks[key * PC + (e ^ rot(key))] = kk8;
         const int c = key >> 5, kk = key & 31;
         const int gg = (kk & 15) >> 2, j = (kk & 3) + (kk >= 16 ? 4 : 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int d = 8 * e + i;
-            vt[(((c * 2 + (d >> 4)) * 64) + (d & 15) + 16 * gg) * 8 + j] = v[i];
+            vt[(((c * DT + (d >> 4)) * 64) + (d & 15) + 16 * gg) * 8 + j] = v[i];
         }
     }
     __syncthreads();
     if (q0 >= NQ) return;
-    f32x4_t o[2][2];   // [dim tile][query tile]
+    f32x4_t o[DT][2];   // [dim tile][query tile]
     float m[2], l[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         m[qt] = -__builtin_inff();
         l[qt] = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) o[dt][qt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     }
     const int live_chunks = (len + 31) / 32;   // chunks beyond the sequence's length hold nothing but masked keys
     // The softmax is what this kernel spends its time on (8 MFMAs per chunk against the vector work of 16 scores per lane),
@@ -146,8 +163,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
         for (int qt = 0; qt < 2; ++qt) {
             const float neg = c == 0 ? 0.f : -m[qt];
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-                s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf[qt], (f32x4_t){neg, neg, neg, neg}, 0, 0, 0);
+            for (int kt = 0; kt < 2; ++kt) {
+                s[kt][qt] = (f32x4_t){neg, neg, neg, neg};
+#pragma unroll
+                for (int ss = 0; ss < KS; ++ss)
+                    s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt][ss], qf[qt][ss], s[kt][qt], 0, 0, 0);
+            }
         }
         // keys at or beyond the length exist only in the sequence's last live chunk: the mask costs nothing elsewhere
         if (32 * c + 32 > len) {
@@ -189,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s[kt][qt][r] -= up;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
             }
@@ -203,8 +224,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
             for (int i = 0; i < 4; ++i) p.h2[i] = __builtin_amdgcn_cvt_pkrtz(e[qt][2 * i], e[qt][2 * i + 1]);
             l[qt] += sum8[qt];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-                o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_vt[(c * 2 + dt) * 64 + lane], p.v, o[dt][qt], 0, 0, 0);
+            for (int dt = 0; dt < DT; ++dt)
+                o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(attn_vt[(c * DT + dt) * 64 + lane], p.v, o[dt][qt], 0, 0, 0);
         }
     }
 #pragma unroll
@@ -214,13 +235,27 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention_hd32_kerne
         lt = col4_sum(lt);
         const float inv = lt > 0.f ? 1.f / lt : 0.f;
         if (q < NQ) {
+            if (a.out_fr) {
+                // the lane's values ARE a B fragment of the output projection (accumulator k order): k-step s = head (HD = 32) or
+                // 2 head + dt / 2 (HD = 64), element j = 4 (dt & 1) + r; row n = seq * NQ + q sits in tile n / 16 at column n % 16
+                const int64_t n = (int64_t)seq * NQ + q;
+                half8_t* dst = reinterpret_cast<half8_t*>(out) + ((n >> 4) * (H / 32) + head * KS) * 64 + 16 * g + (int)(n & 15);
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-                half4_t w;
+                for (int s2 = 0; s2 < KS; ++s2) {
+                    half8_t w;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][qt][r] * inv);
-                *reinterpret_cast<half4_t*>(out + ((int64_t)seq * NQ + q) * H + head * kAttnHeadDim + 16 * dt + 4 * g) = w;
+                    for (int j = 0; j < 8; ++j) w[j] = (_Float16)(o[2 * s2 + (j >> 2)][qt][j & 3] * inv);
+                    dst[s2 * 64] = w;
+                }
+            } else {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                    half4_t w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r] = (_Float16)(o[dt][qt][r] * inv);
+                    *reinterpret_cast<half4_t*>(out + ((int64_t)seq * NQ + q) * H + head * HD + 16 * dt + 4 * g) = w;
+                }
             }
         }
     }

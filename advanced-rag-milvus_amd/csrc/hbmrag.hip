@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "attention.h"
+#include "encoder_layer.h"
 #include "dense.h"
 #include "encoder_ops.h"
 #include "filter.h"
@@ -1893,41 +1894,49 @@ int hr_embed_layernorm_f16_dev(const int64_t* d_ids, const int64_t* d_types, con
 
 static int attention_launch(const _Float16* q, int64_t q_seq, int64_t q_tok, const _Float16* k, const _Float16* v, int64_t kv_seq,
                             int64_t kv_tok, const int32_t* d_lengths, _Float16* out, int64_t n_seq, int T, int n_queries, int heads,
-                            int head_dim, float scale, hipStream_t stream) {
+                            int head_dim, float scale, hipStream_t stream, bool out_fr = false) {
     if (n_seq < 0 || T <= 0 || heads <= 0 || n_queries <= 0 || n_queries > T) return fail(nullptr, HR_EINVAL, "bad attention sizes");
-    if (head_dim != kAttnHeadDim) return fail(nullptr, HR_ELIMIT, "this attention kernel serves head dimension %d only (got %d)", kAttnHeadDim, head_dim);
-    if (T > kAttnMaxT) return fail(nullptr, HR_ELIMIT, "sequence length %d exceeds %d", T, kAttnMaxT);
+    if (head_dim != 32 && head_dim != 64) return fail(nullptr, HR_ELIMIT, "the attention kernels serve head dimensions 32 and 64 (got %d)", head_dim);
+    const int max_t = kAttnLdsBytes / (4 * head_dim);                  // K + V of a (sequence, head) must fit the block's LDS
+    if (T > max_t) return fail(nullptr, HR_ELIMIT, "sequence length %d exceeds %d at head dimension %d", T, max_t, head_dim);
     if (!q || !k || !v || !out) return fail(nullptr, HR_EINVAL, "null buffer");
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15) return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
     if ((q_seq | q_tok | kv_seq | kv_tok) & 7) return fail(nullptr, HR_EINVAL, "strides must be multiples of 8 halves");
     if (n_seq == 0) return HR_OK;
     if (n_seq * heads > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many (sequence, head) pairs");
     const int n_chunks = (T + 31) / 32;
-    const size_t lds = (size_t)n_chunks * 32 * 128;   // K and V^T of a (sequence, head)
+    const size_t lds = (size_t)n_chunks * 32 * 4 * head_dim;           // K and V^T of a (sequence, head)
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e0 = hipFuncSetAttribute((const void*)attention_hd32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnMaxT * 128);
-        if (e0 == hipSuccess)
-            e0 = hipFuncSetAttribute((const void*)attention_hd32_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnMaxT * 128);
-        if (e0 != hipSuccess) return fail(nullptr, HR_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e0));
+        const void* kernels[4] = {(const void*)attention_kernel<4, 32>, (const void*)attention_kernel<8, 32>,
+                                  (const void*)attention_kernel<4, 64>, (const void*)attention_kernel<8, 64>};
+        for (const void* f : kernels) {
+            hipError_t e0 = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kAttnLdsBytes);
+            if (e0 != hipSuccess) return fail(nullptr, HR_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e0));
+        }
         attr_set = true;
     }
     const int NW = n_queries <= 128 ? 4 : 8;                           // waves (x 32 queries) per block
+    const int HG = head_dim == 32 ? 2 : 1;                             // heads per 128-byte line of the QKV buffer
     AttnArgs a{};
     a.q = q; a.k = k; a.v = v; a.out = out; a.lengths = d_lengths;
     a.q_seq = q_seq; a.q_tok = q_tok; a.kv_seq = kv_seq; a.kv_tok = kv_tok;
     a.T = T; a.n_queries = n_queries; a.heads = heads;
     a.n_qblocks = (n_queries + 32 * NW - 1) / (32 * NW);
-    a.n_pairs = n_seq * ((heads + 1) / 2);                             // head pairs: the blocks of a pair share an XCD
+    a.n_pairs = n_seq * ((heads + HG - 1) / HG);                       // head groups: the blocks of a group share an XCD
     a.scale_log2e = scale * 1.4426950408889634f;
-    const int64_t n_blocks = ((a.n_pairs + 7) / 8) * 8 * 2 * a.n_qblocks;
+    a.out_fr = out_fr ? 1 : 0;
+    const int64_t n_blocks = ((a.n_pairs + 7) / 8) * 8 * HG * a.n_qblocks;
     if (n_blocks > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many attention blocks");
-    if (NW == 4)
-        hipLaunchKernelGGL(attention_hd32_kernel<4>, dim3((unsigned)n_blocks), dim3(256), lds, stream, a);
-    else
-        hipLaunchKernelGGL(attention_hd32_kernel<8>, dim3((unsigned)n_blocks), dim3(512), lds, stream, a);
+    if (head_dim == 32) {
+        if (NW == 4) hipLaunchKernelGGL((attention_kernel<4, 32>), dim3((unsigned)n_blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((attention_kernel<8, 32>), dim3((unsigned)n_blocks), dim3(512), lds, stream, a);
+    } else {
+        if (NW == 4) hipLaunchKernelGGL((attention_kernel<4, 64>), dim3((unsigned)n_blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((attention_kernel<8, 64>), dim3((unsigned)n_blocks), dim3(512), lds, stream, a);
+    }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "attention_hd32_kernel: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "attention_kernel: %s", hipGetErrorString(e));
     return HR_OK;
 }
 
@@ -1940,12 +1949,85 @@ int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_ou
                             n_seq, T, T, heads, head_dim, scale, (hipStream_t)stream);
 }
 
+int hr_attention_fr_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out_fr, int64_t n_seq, int T, int heads,
+                            int head_dim, float scale, void* stream) {
+    if (!d_qkv) return fail(nullptr, HR_EINVAL, "null buffer");
+    const int64_t H = (int64_t)heads * head_dim;
+    if (H % 32 != 0) return fail(nullptr, HR_EINVAL, "fragment-order output needs a hidden size that is a multiple of 32");
+    const _Float16* qkv = (const _Float16*)d_qkv;
+    return attention_launch(qkv, (int64_t)T * 3 * H, 3 * H, qkv + H, qkv + 2 * H, (int64_t)T * 3 * H, 3 * H, d_lengths, (_Float16*)d_out_fr,
+                            n_seq, T, T, heads, head_dim, scale, (hipStream_t)stream, true);
+}
+
 int hr_attention_rows_f16_dev(const void* d_q, int64_t q_seq_stride, int64_t q_token_stride, const void* d_k, const void* d_v,
                               int64_t kv_seq_stride, int64_t kv_token_stride, const int32_t* d_lengths, void* d_out, int64_t n_seq,
                               int T, int n_queries, int heads, int head_dim, float scale, void* stream) {
     return attention_launch((const _Float16*)d_q, q_seq_stride, q_token_stride, (const _Float16*)d_k, (const _Float16*)d_v, kv_seq_stride,
                             kv_token_stride, d_lengths, (_Float16*)d_out, n_seq, T, n_queries, heads, head_dim, scale,
                             (hipStream_t)stream);
+}
+
+// ---- encoder layer kernels (csrc/encoder_layer.h) -----------------------------------------------------------------
+static int el_allow_lds(const void* kernel, size_t bytes) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return e == hipSuccess ? HR_OK : fail(nullptr, HR_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+}
+
+int hr_linear_rows_f16_dev(const void* d_x, int x_fr, const void* d_w_packed, const float* d_bias, void* d_out, int64_t rows, int K, int N,
+                           int64_t out_stride, void* stream) {
+    if (rows < 0 || K <= 0 || N <= 0 || N % 32 != 0 || out_stride < N || out_stride % 4 != 0) return fail(nullptr, HR_EINVAL, "bad linear sizes");
+    if (K != 384) return fail(nullptr, HR_ELIMIT, "the hand-written linear kernel serves K = 384 (got %d)", K);
+    if (N > 4096) return fail(nullptr, HR_ELIMIT, "N exceeds 4096");
+    if (!d_x || !d_w_packed || !d_bias || !d_out) return fail(nullptr, HR_EINVAL, "null buffer");
+    if (((uintptr_t)d_x | (uintptr_t)d_w_packed | (uintptr_t)d_bias | (uintptr_t)d_out) & 15) return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
+    if (rows == 0) return HR_OK;
+    constexpr int KS = 12, TT = 2;
+    const size_t lds = (size_t)(kElRingStages + 1) * 2 * KS * 1024 + (size_t)N * 4;
+    static bool ready = false;
+    if (!ready) {
+        HR_TRY(el_allow_lds((const void*)linear_rows_kernel<KS, TT>, 160 * 1024));
+        ready = true;
+    }
+    LinearArgs a{};
+    a.x = (const _Float16*)d_x; a.w = (const chunk_t*)d_w_packed; a.bias = d_bias; a.out = (_Float16*)d_out;
+    a.M = rows; a.out_stride = out_stride; a.N = N; a.x_fr = x_fr ? 1 : 0;
+    const int64_t blocks = (rows + 64 * TT - 1) / (64 * TT);
+    if (blocks > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many rows");
+    hipLaunchKernelGGL((linear_rows_kernel<KS, TT>), dim3((unsigned)blocks), dim3(64 * kElWaves), lds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "linear_rows_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_encoder_tail_f16_dev(const void* d_attn_fr, const void* d_x, int x_fr, void* d_out, int out_fr, const void* d_wstream,
+                            const float* d_tables, int64_t rows, int hidden, int intermediate, float eps, int gelu_erf, void* stream) {
+    if (rows < 0 || hidden <= 0 || intermediate <= 0) return fail(nullptr, HR_EINVAL, "bad encoder-tail sizes");
+    if (hidden != 384 || intermediate != 1536)
+        return fail(nullptr, HR_ELIMIT, "the fused layer tail serves (hidden, intermediate) = (384, 1536) (got %d, %d)", hidden, intermediate);
+    if (!d_attn_fr || !d_x || !d_out || !d_wstream || !d_tables) return fail(nullptr, HR_EINVAL, "null buffer");
+    if (((uintptr_t)d_attn_fr | (uintptr_t)d_x | (uintptr_t)d_out | (uintptr_t)d_wstream | (uintptr_t)d_tables) & 15)
+        return fail(nullptr, HR_EINVAL, "buffers must be 16-byte aligned");
+    if (rows == 0) return HR_OK;
+    constexpr int HS = 12, IS = 48, TT = 2;
+    const size_t lds = (size_t)kElRingStages * 2 * HS * 1024 + (size_t)(6 * hidden + intermediate) * 4;
+    static bool ready = false;
+    if (!ready) {
+        HR_TRY(el_allow_lds((const void*)encoder_tail_kernel<HS, IS, TT, false>, 160 * 1024));
+        HR_TRY(el_allow_lds((const void*)encoder_tail_kernel<HS, IS, TT, true>, 160 * 1024));
+        ready = true;
+    }
+    TailArgs a{};
+    a.a = (const _Float16*)d_attn_fr; a.x = (const _Float16*)d_x; a.out = (_Float16*)d_out; a.x_fr = x_fr ? 1 : 0; a.out_fr = out_fr ? 1 : 0;
+    a.wstream = (const chunk_t*)d_wstream; a.tables = d_tables; a.M = rows; a.eps = eps;
+    const int64_t blocks = (rows + 64 * TT - 1) / (64 * TT);
+    if (blocks > 0x7fffffffll) return fail(nullptr, HR_ELIMIT, "too many rows");
+    if (gelu_erf)
+        hipLaunchKernelGGL((encoder_tail_kernel<HS, IS, TT, true>), dim3((unsigned)blocks), dim3(64 * kElWaves), lds, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((encoder_tail_kernel<HS, IS, TT, false>), dim3((unsigned)blocks), dim3(64 * kElWaves), lds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "encoder_tail_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
 }
 
 // ---- host-buffer, synchronous forms -------------------------------------------------

@@ -327,11 +327,11 @@ HR_API int hr_embed_layernorm_f16_dev(const int64_t* d_ids, const int64_t* d_typ
                                const void* d_seg, const void* d_gamma, const void* d_beta, void* d_out, int64_t n_seq, int T,
                                int hidden, float eps, int64_t n_word, int64_t n_seg, void* stream);
 
-/* Self-attention for head dimension 32, from the fused QKV projection's output to the layout the output projection
- * reads (the PyTorch SDPA call plus the permute / transpose copies around it, in one kernel):
- *   d_qkv [n_seq][T][3][heads][32] fp16, d_lengths[n_seq] valid tokens per sequence (padding at the tail; NULL = T),
- *   d_out [n_seq][T][heads * 32] fp16 = softmax(scale * Q K^T, keys < length) V per head, fp32 accumulation.
- * T <= 1024 (K and V of a (sequence, head) are staged in LDS); HR_ELIMIT beyond. */
+/* Self-attention for head dimensions 32 and 64, from the fused QKV projection's output to the layout the output
+ * projection reads (the PyTorch SDPA call plus the permute / transpose copies around it, in one kernel):
+ *   d_qkv [n_seq][T][3][heads][head_dim] fp16, d_lengths[n_seq] valid tokens per sequence (padding at the tail; NULL = T),
+ *   d_out [n_seq][T][heads * head_dim] fp16 = softmax(scale * Q K^T, keys < length) V per head, fp32 accumulation.
+ * T <= 1024 at head_dim 32, <= 512 at 64 (K and V of a (sequence, head) are staged in LDS); HR_ELIMIT beyond. */
 HR_API int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out, int64_t n_seq, int T, int heads,
                          int head_dim, float scale, void* stream);
 /* The same kernel with its operands by pointer and stride (in halves, multiples of 8): query rows at
@@ -342,6 +342,43 @@ HR_API int hr_attention_f16_dev(const void* d_qkv, const int32_t* d_lengths, voi
 HR_API int hr_attention_rows_f16_dev(const void* d_q, int64_t q_seq_stride, int64_t q_token_stride, const void* d_k, const void* d_v,
                               int64_t kv_seq_stride, int64_t kv_token_stride, const int32_t* d_lengths, void* d_out,
                               int64_t n_seq, int T, int n_queries, int heads, int head_dim, float scale, void* stream);
+
+/* ---- encoder / cross-encoder layer: the linear maps as hand-written MFMA kernels (round 4) ---------------------------
+ * The forward passes behind the reference's plugin hooks (`CrossEncoderReranker.model.predict`, retrieval.py:651-685;
+ * `embedding_generator.encode_semantic`, indexing.py:610-620) are post-LN BERT layers.  These two entry points are the
+ * GEMM-shaped part of a layer (csrc/encoder_layer.h): weights travel as PACKED streams of 1 KiB pieces — one
+ * v_mfma_f32_16x16x32_f16 A fragment (16 output features x 32 inputs) in register-image order: lane l = 16 g + r of the
+ * piece holds 8 consecutive halves of row 16 t + r —
+ *   natural k order:      inputs 32 s + 8 g + j,                                    j = 0..7
+ *   accumulator k order:  inputs 32 s + (j < 4 ? 4 g + j : 16 + 4 g + j - 4)        (the operand comes out of an MFMA)
+ * built once per model by advanced_rag/encoder_kernels.py.  fp16 activations, fp32 accumulation, fp32 biases / LayerNorm
+ * parameters.  All pointers are device pointers, 16-byte aligned.
+ *
+ * FRAGMENT ORDER ("FR") is the activation layout between the launches of a layer: X_fr[tile = row / 16][s][lane = 16 g + c][j]
+ * = X[16 tile + c][32 s + 16 (j >> 2) + 4 g + (j & 3)], 1 KiB per (16-row tile, k-step); buffers hold ceil(rows / 16) tiles.
+ * It is the accumulator layout of two neighbouring output tiles AND the B operand of the next product in accumulator k
+ * order, so rows move with 16-byte accesses contiguous over the wave.  Row-major stays available per operand.
+ *
+ * hr_linear_rows_f16_dev:  d_out[r][0..N) (row-major, row stride out_stride halves) = x[r][0..K) W^T + bias.  d_x: row-major
+ *   [rows][K] (x_fr = 0: d_w_packed pieces [N/16][K/32] in natural k order) or FR (x_fr = 1: accumulator k order).
+ *   N a multiple of 32 (<= 4096); K = 384 (HR_ELIMIT otherwise: callers keep their GEMM).
+ * hr_attention_fr_f16_dev: hr_attention_f16_dev with its output in FR ([rows = n_seq * T][heads * head_dim]).
+ * hr_encoder_tail_f16_dev: out = LN2(x1 + W_down gelu(W_up x1 + b_up) + b_down), x1 = LN1(x + W_out attn + b_out)
+ *   for rows of `hidden` halves: everything of a layer after the attention in ONE launch; the [rows][intermediate] FFN
+ *   intermediate never leaves the compute unit.  d_attn_fr: FR.  d_x / d_out: FR or row-major per x_fr / out_fr.
+ *   d_wstream: stages of hidden/16 pieces, ALL in accumulator k order —
+ *     W_out, two output tiles per stage: hidden/32 stages;  then, with up(c) = output tiles 2c, 2c+1 of W_up [all k-steps]
+ *     and down(c) = k-step c of every output tile of W_down:
+ *     up(0) | up(1) down(0) | up(2) down(1) | ... | up(I/32-1) down(I/32-2) | down(I/32-1).
+ *   d_tables (fp32): b_out[H] ln1_gamma[H] ln1_beta[H] b_down[H] ln2_gamma[H] ln2_beta[H] b_up[I].
+ *   gelu_erf: 0 = tanh form, 1 = exact erf form.  (hidden, intermediate) = (384, 1536) (HR_ELIMIT otherwise). */
+HR_API int hr_linear_rows_f16_dev(const void* d_x, int x_fr, const void* d_w_packed, const float* d_bias, void* d_out, int64_t rows,
+                           int K, int N, int64_t out_stride, void* stream);
+HR_API int hr_attention_fr_f16_dev(const void* d_qkv, const int32_t* d_lengths, void* d_out_fr, int64_t n_seq, int T, int heads,
+                            int head_dim, float scale, void* stream);
+HR_API int hr_encoder_tail_f16_dev(const void* d_attn_fr, const void* d_x, int x_fr, void* d_out, int out_fr, const void* d_wstream,
+                            const float* d_tables, int64_t rows, int hidden, int intermediate, float eps, int gelu_erf,
+                            void* stream);
 
 /* ---- streams with a compute-unit mask -------------------------------------------
  * A HIP stream whose kernels may only occupy the compute units named by `cu_mask` (bit i of word i/32 = CU i;

@@ -282,16 +282,18 @@ def test_device_embedding_table_evicts_fifo_and_keeps_values(gpu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("grow", [0.0, 1.0])
-@pytest.mark.parametrize("n_seq,T,heads", [(3, 16, 1), (5, 40, 4), (7, 128, 12), (2, 200, 3), (2, 512, 12), (1, 8, 2), (9, 129, 5),
-                                           (2, 1024, 2), (11, 300, 7)])
-def test_attention_hd32_kernel_matches_sdpa_fp32(gpu, n_seq, T, heads, grow):
-    """hr_attention_f16_dev (head dimension 32: QK^T, masked online softmax and PV on the MFMA units, from the fused
+@pytest.mark.parametrize("n_seq,T,heads,hd", [(3, 16, 1, 32), (5, 40, 4, 32), (7, 128, 12, 32), (2, 200, 3, 32), (2, 512, 12, 32),
+                                              (1, 8, 2, 32), (9, 129, 5, 32), (2, 1024, 2, 32), (11, 300, 7, 32),
+                                              (3, 16, 1, 64), (5, 40, 4, 64), (7, 128, 12, 64), (2, 200, 3, 64), (2, 512, 12, 64),
+                                              (1, 8, 2, 64), (9, 129, 5, 64), (3, 300, 16, 64)])
+def test_attention_kernel_matches_sdpa_fp32(gpu, n_seq, T, heads, hd, grow):
+    """hr_attention_f16_dev (head dimensions 32 and 64: QK^T, masked online softmax and PV on the MFMA units, from the fused
     QKV buffer to the [tokens, hidden] layout) against PyTorch's scaled_dot_product_attention in fp32 on the same
     fp16-rounded inputs, ragged sequence lengths (keys at or beyond the length masked): within fp16 output rounding."""
     from advanced_rag import _native as nat
-    g = torch.Generator(device="cuda").manual_seed(n_seq * 1000 + T)
-    H = heads * 32
-    qkv = (torch.randn((n_seq, T, 3, heads, 32), device="cuda", generator=g) * 1.5)
+    g = torch.Generator(device="cuda").manual_seed(n_seq * 1000 + T + hd)
+    H = heads * hd
+    qkv = (torch.randn((n_seq, T, 3, heads, hd), device="cuda", generator=g) * (1.5 if hd == 32 else 1.25))
     # grow = 1: keys that double along the sequence — the scores of later chunks exceed the reference maximum of the
     # earlier ones by more than 2^8, so the rescale branch of the kernel's lazy softmax runs in the middle of sequences
     # too.  Scores then reach ~30 (log2 units) and the fp16 rounding of the pre-scaled Q (2^-11 relative) is worth 1 - 2 %
@@ -302,7 +304,7 @@ def test_attention_hd32_kernel_matches_sdpa_fp32(gpu, n_seq, T, heads, grow):
     lengths = torch.randint(1, T + 1, (n_seq,), device="cuda", generator=g).to(torch.int32)
     lengths[0] = T
     out = torch.full((n_seq, T, H), float("nan"), dtype=torch.float16, device="cuda")
-    nat.attention_f16_dev(qkv.data_ptr(), lengths.data_ptr(), out.data_ptr(), n_seq, T, heads, 32, 32 ** -0.5,
+    nat.attention_f16_dev(qkv.data_ptr(), lengths.data_ptr(), out.data_ptr(), n_seq, T, heads, hd, hd ** -0.5,
                           torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     q, k, v = qkv.float().permute(2, 0, 3, 1, 4)
@@ -312,22 +314,185 @@ def test_attention_hd32_kernel_matches_sdpa_fp32(gpu, n_seq, T, heads, grow):
     assert torch.isfinite(out).all()
     assert torch.allclose(out.float(), want, atol=atol, rtol=rtol), (out.float() - want).abs().max()
     # no lengths = every key is valid
-    nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), n_seq, T, heads, 32, 32 ** -0.5, torch.cuda.current_stream().cuda_stream)
+    nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), n_seq, T, heads, hd, hd ** -0.5, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     want = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(n_seq, T, H)
     assert torch.allclose(out.float(), want, atol=atol, rtol=rtol)
-    with pytest.raises(nat.HbmRagError):
-        nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), n_seq, T, heads, 64, 0.125, 0)
-    # operands by pointer and stride: the first nq tokens as queries over a separate [n_seq, T, 2, heads, 32] K / V buffer
+    # fragment-order output (what the fused layer tail reads): the same values, the other layout
+    from advanced_rag.encoder_kernels import fr_rows, from_fragment_order
+    ofr = torch.zeros((fr_rows(n_seq * T), H), dtype=torch.float16, device="cuda")
+    nat.attention_fr_f16_dev(qkv.data_ptr(), 0, ofr.data_ptr(), n_seq, T, heads, hd, hd ** -0.5, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    # (the two store paths round the normalised output through different instruction pairs: a last-place difference here and there)
+    assert torch.allclose(from_fragment_order(ofr, n_seq * T).float(), out.reshape(n_seq * T, H).float(), atol=2.5e-4, rtol=1e-3)
+    with pytest.raises(nat.HbmRagError):   # head dimensions other than 32 / 64 are refused, not approximated
+        nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), n_seq, T, heads, 48, 0.125, 0)
+    # operands by pointer and stride: the first nq tokens as queries over a separate [n_seq, T, 2, heads, hd] K / V buffer
     kvbuf = qkv[:, :, 1:].contiguous()
     for nq in sorted({1, min(T, 33), min(T, 160)}):
-        qrows = qkv[:, :nq, 0].contiguous()                                   # [n_seq, nq, heads, 32]
+        qrows = qkv[:, :nq, 0].contiguous()                                   # [n_seq, nq, heads, hd]
         o2 = torch.full((n_seq, nq, H), float("nan"), dtype=torch.float16, device="cuda")
         nat.attention_rows_f16_dev(qrows.data_ptr(), nq * H, H, kvbuf.data_ptr(), kvbuf.data_ptr() + 2 * H, T * 2 * H, 2 * H,
-                                   lengths.data_ptr(), o2.data_ptr(), n_seq, T, nq, heads, 32, 32 ** -0.5,
+                                   lengths.data_ptr(), o2.data_ptr(), n_seq, T, nq, heads, hd, hd ** -0.5,
                                    torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         w2 = torch.nn.functional.scaled_dot_product_attention(q[:, :, :nq], k, v, attn_mask=bias).transpose(1, 2).reshape(n_seq, nq, H)
         assert torch.allclose(o2.float(), w2, atol=atol, rtol=rtol), (nq, (o2.float() - w2).abs().max())
     with pytest.raises(nat.HbmRagError):   # K and V of a (sequence, head) must fit LDS
-        nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), 1, 1025, heads, 32, 0.125, 0)
+        nat.attention_f16_dev(qkv.data_ptr(), 0, out.data_ptr(), 1, 1025 if hd == 32 else 513, heads, hd, 0.125, 0)
+
+
+# --------------------------------------------------------------------------- hand-written layer kernels (round 4)
+def test_weight_packers_follow_the_documented_index_formulas():
+    """encoder_kernels.pack_natural / pack_accumulator_order / pack_tail_stream against the element-by-element definitions
+    of include/hbmrag.h (CPU: pure reshapes)."""
+    from advanced_rag.encoder_kernels import pack_accumulator_order, pack_natural, pack_tail_stream
+    N, K = 48, 96
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 2039          # exactly representable in fp16
+    nat_p = pack_natural(w).reshape(N // 16, K // 32, 4, 16, 8)
+    acc_p = pack_accumulator_order(w).reshape(N // 16, K // 32, 4, 16, 8)
+    for t in range(N // 16):
+        for s in range(K // 32):
+            for g in range(4):
+                for r in (0, 7, 15):
+                    for j in range(8):
+                        assert nat_p[t, s, g, r, j] == w[16 * t + r, 32 * s + 8 * g + j]
+                        kk = 32 * s + (4 * g + j if j < 4 else 16 + 4 * g + j - 4)
+                        assert acc_p[t, s, g, r, j] == w[16 * t + r, kk]
+    H, I = 64, 128
+    gen = torch.Generator().manual_seed(5)
+    w_out, w_up, w_down = (torch.randn(shape, generator=gen).half().float() for shape in ((H, H), (I, H), (H, I)))
+    stream = pack_tail_stream(w_out, w_up, w_down).reshape(-1, H // 16, 512)   # [stage][piece][halves]
+    n = I // 32
+    assert stream.shape[0] == H // 32 + 2 * n
+    out_p = pack_accumulator_order(w_out).reshape(H // 16, H // 32, 512)    # the attention output arrives in fragment order
+    up_p = pack_accumulator_order(w_up).reshape(I // 16, H // 32, 512)
+    down_p = pack_accumulator_order(w_down).reshape(H // 16, I // 32, 512)
+    hs = H // 32
+    for so in range(hs):                                                        # two output tiles of W_out per stage
+        assert torch.equal(stream[so].reshape(2, hs, 512), out_p[2 * so: 2 * so + 2])
+    order = [("up", 0)] + [x for c in range(n - 1) for x in (("up", c + 1), ("down", c))] + [("down", n - 1)]
+    for i, (kind, c) in enumerate(order):
+        got = stream[hs + i]
+        if kind == "up":
+            assert torch.equal(got.reshape(2, hs, 512), up_p[2 * c: 2 * c + 2])
+        else:
+            assert torch.equal(got, down_p[:, c])
+    # fragment order of activations: X_fr[tile][s][16 g + c][j] = X[16 tile + c][32 s + 16 (j >> 2) + 4 g + (j & 3)]
+    from advanced_rag.encoder_kernels import fr_rows, from_fragment_order, to_fragment_order
+    M, Hx = 37, 96
+    x = (torch.arange(M * Hx, dtype=torch.float32).reshape(M, Hx) % 2039).half()
+    fr = to_fragment_order(x)
+    assert fr.shape == (fr_rows(M), Hx) == (48, 96)
+    v = fr.reshape(3, Hx // 32, 4, 16, 8)
+    for tile, s_, g_, c_, j in ((0, 0, 0, 0, 0), (1, 2, 3, 5, 6), (2, 1, 2, 4, 3), (0, 2, 1, 15, 7)):
+        row = 16 * tile + c_
+        assert v[tile, s_, g_, c_, j] == (x[row, 32 * s_ + 16 * (j >> 2) + 4 * g_ + (j & 3)] if row < M else 0)
+    assert torch.equal(from_fragment_order(fr, M), x)
+
+
+def _ref_layer_tail(a, x, layer, gelu):
+    """fp32 arithmetic of everything after the attention on fp16-rounded operands."""
+    f = lambda t: t.float()   # noqa: E731
+    x1 = torch.nn.functional.layer_norm(f(x) + f(a) @ f(layer.out.weight).t() + f(layer.out.bias), (x.shape[-1],),
+                                        f(layer.ln1.weight), f(layer.ln1.bias), layer.ln1.eps)
+    x1 = x1.half().float()                                     # the kernel hands x1 to the FFN (and the residual) as fp16
+    h = x1 @ f(layer.up.weight).t() + f(layer.up.bias)
+    h = torch.nn.functional.gelu(h, approximate="tanh" if gelu == "tanh" else "none").half().float()
+    y = x1 + h @ f(layer.down.weight).t() + f(layer.down.bias)
+    return torch.nn.functional.layer_norm(y, (x.shape[-1],), f(layer.ln2.weight), f(layer.ln2.bias), layer.ln2.eps)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [1, 127, 128, 129, 1000, 4096 + 77])
+def test_linear_rows_kernel_matches_fp32(gpu, rows):
+    """hr_linear_rows_f16_dev (K = 384; N = 1152 the QKV projection, 768 keys + values, 32 the smallest) against an fp32
+    matmul of the same fp16-rounded operands; ragged row counts, a strided output."""
+    from advanced_rag.encoder_kernels import linear_rows, pack_accumulator_order, pack_natural, to_fragment_order
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    x = torch.randn((rows, 384), device="cuda", generator=g).half()
+    for N in (1152, 768, 32):
+        w = (torch.randn((N, 384), device="cuda", generator=g) * 0.05).half()
+        b = torch.randn((N,), device="cuda", generator=g)
+        want = x.float() @ w.float().t() + b
+        out = torch.full((rows, N + 8), float("nan"), dtype=torch.float16, device="cuda")
+        linear_rows(x, pack_natural(w), b, N, out=out[:, :N])
+        torch.cuda.synchronize()
+        assert torch.isnan(out[:, N:]).all()                 # nothing written beyond the N columns of a strided row
+        assert torch.allclose(out[:, :N].float(), want, atol=4e-3, rtol=4e-3), (N, (out[:, :N].float() - want).abs().max())
+        # the same rows handed over in fragment order, the weights in accumulator k order (another summation order inside
+        # the MFMA: equal up to fp32 rounding)
+        out2 = linear_rows(to_fragment_order(x), pack_accumulator_order(w), b, N, rows=rows, x_fr=True)
+        torch.cuda.synchronize()
+        assert torch.allclose(out2.float(), want, atol=4e-3, rtol=4e-3)
+        assert (out2.float() - out[:, :N].float()).abs().max() <= 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gelu", ["tanh", "erf"])
+@pytest.mark.parametrize("rows", [1, 128, 200, 2560 + 33])
+def test_encoder_tail_kernel_matches_fp32(gpu, rows, gelu):
+    """hr_encoder_tail_f16_dev — output projection + residual + LayerNorm + FFN (tanh / erf GELU) + residual + LayerNorm in
+    one launch, the FFN intermediate kept on chip — against fp32 PyTorch on the same fp16-rounded operands, with
+    non-trivial LayerNorm parameters and biases (random-init models have gamma = 1, beta = 0, bias = 0)."""
+    from advanced_rag.encoder_kernels import LayerKernels, encoder_tail, from_fragment_order, to_fragment_order
+    from advanced_rag.encoders import _Layer
+    torch.manual_seed(rows)
+    layer = _Layer(EncoderConfig(gelu=gelu))
+    with torch.no_grad():
+        for lin in (layer.qkv, layer.out, layer.up, layer.down):
+            lin.weight.normal_(0, 0.05)
+            lin.bias.normal_(0, 0.1)
+        for ln in (layer.ln1, layer.ln2):
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.normal_(0, 0.2)
+    layer = layer.to("cuda", torch.float16)
+    g = torch.Generator(device="cuda").manual_seed(rows + 1)
+    a = torch.randn((rows, 384), device="cuda", generator=g).half()
+    x = torch.randn((rows, 384), device="cuda", generator=g).half()
+    k = LayerKernels().ensure(layer)
+    out = encoder_tail(to_fragment_order(a), x, k, 1536, layer.ln1.eps, gelu == "erf")
+    torch.cuda.synchronize()
+    want = _ref_layer_tail(a, x, layer, gelu)
+    assert torch.isfinite(out).all()
+    err = (out.float() - want).abs()
+    assert torch.allclose(out.float(), want, atol=1.5e-2, rtol=1.5e-2), (err.max(), err.mean())
+    assert err.mean() < 1.5e-3                                # fp16 output rounding of O(1) values is ~2e-4 on average
+    # residual and output in fragment order: the same bits as row-major
+    out_fr = encoder_tail(to_fragment_order(a), to_fragment_order(x), k, 1536, layer.ln1.eps, gelu == "erf", rows=rows, x_fr=True,
+                          out_fr=True)
+    torch.cuda.synchronize()
+    assert torch.equal(from_fragment_order(out_fr, rows), out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [16, 128, 200])
+def test_layer_kernels_equal_the_unfused_forward(gpu, T):
+    """A whole MiniLM-shaped model with the three hand-written launches per layer against the same weights through the
+    PyTorch GEMMs + fused elementwise kernels (use_layer_kernels = False) and against fp32: cross-encoder logits (the last
+    layer for token 0 only) and sentence embeddings, ragged lengths."""
+    ce = CrossEncoderModel(EncoderConfig(), device="cuda:0", seed=5)
+    n = 37
+    g = torch.Generator(device="cuda").manual_seed(T)
+    ids = torch.randint(1000, 30000, (n, T), device="cuda", generator=g)
+    ids[:, 0] = 101
+    types = (torch.arange(T, device="cuda")[None, :] >= T // 3).long().expand(n, T).contiguous()
+    mask = torch.arange(T, device="cuda")[None, :] < torch.randint(2, T + 1, (n, 1), device="cuda", generator=g)
+    mask[0] = True
+    ids = ids.masked_fill(~mask, 0)
+    with torch.inference_mode():
+        fused = ce.module(ids, types, mask)
+        for layer in ce.module.encoder.layers:
+            layer.use_layer_kernels = False
+        plain = ce.module(ids, types, mask)
+        ref = CrossEncoderModel(EncoderConfig(), device="cuda:0", dtype=torch.float32, seed=5)
+        want = ref.module(ids, types, mask)
+    assert torch.allclose(fused, want, atol=3e-2, rtol=3e-2), (fused - want).abs().max()
+    assert (fused - want).abs().max() <= 2.0 * (plain - want).abs().max() + 5e-3   # no worse than the fp16 GEMM path
+    enc = SentenceEncoder(EncoderConfig(), device="cuda:0", seed=6)
+    with torch.inference_mode():
+        e1 = enc.module(ids, types, mask)
+        for layer in enc.module.encoder.layers:
+            layer.use_layer_kernels = False
+        e2 = enc.module(ids, types, mask)
+    assert torch.allclose(e1, e2, atol=5e-3), (e1 - e2).abs().max()
