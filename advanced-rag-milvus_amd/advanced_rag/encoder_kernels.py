@@ -42,6 +42,22 @@ def pack_accumulator_order(w: torch.Tensor) -> torch.Tensor:
     return v.permute(0, 2, 4, 1, 3, 5).contiguous().reshape(-1)           # [t][s][g][r][hi][jj] -> j = 4 hi + jj
 
 
+def store_order_rows(n: int, device=None) -> torch.Tensor:
+    """Row permutation of a weight matrix (and its bias) for hr_linear_rows_f16_dev: packed row 32 so + 16 u + r holds output
+    feature 32 so + 8 (r >> 2) + 4 u + (r & 3), so that a lane's eight results of a stage are eight consecutive features."""
+    assert n % 32 == 0
+    i = torch.arange(n, device=device)
+    so, u, r = i // 32, (i // 16) % 2, i % 16
+    return 32 * so + 8 * (r // 4) + 4 * u + (r % 4)
+
+
+def pack_linear(w: torch.Tensor, bias: torch.Tensor, fragment_order_input: bool):
+    """-> (packed weights, fp32 bias) of hr_linear_rows_f16_dev for row-major (natural k order) or fragment-order input."""
+    perm = store_order_rows(w.shape[0], w.device)
+    wp = w[perm]
+    return (pack_accumulator_order(wp) if fragment_order_input else pack_natural(wp)), bias[perm].to(torch.float32).contiguous()
+
+
 def pack_tail_stream(w_out: torch.Tensor, w_up: torch.Tensor, w_down: torch.Tensor) -> torch.Tensor:
     """The weight stream of hr_encoder_tail_f16_dev (include/hbmrag.h): W_out | up(0) | up(1) down(0) | ... | down(last)."""
     H, I = w_out.shape[0], w_up.shape[0]
@@ -82,12 +98,11 @@ class LayerKernels:
         if key != self._key:
             H = layer.out.weight.shape[0]
             with torch.no_grad():
-                self.qkv_w = pack_natural(layer.qkv.weight)               # for row-major input
-                self.qkv_w_fr = pack_accumulator_order(layer.qkv.weight)  # for fragment-order input
-                self.qkv_b = layer.qkv.bias.to(torch.float32).contiguous()
-                self.kv_w = pack_natural(layer.qkv.weight[H:])            # keys and values only (the last layer of a cross-encoder)
-                self.kv_w_fr = pack_accumulator_order(layer.qkv.weight[H:])
-                self.kv_b = layer.qkv.bias[H:].to(torch.float32).contiguous()
+                self.qkv_w, self.qkv_b = pack_linear(layer.qkv.weight, layer.qkv.bias, False)      # row-major input
+                self.qkv_w_fr, _ = pack_linear(layer.qkv.weight, layer.qkv.bias, True)             # fragment-order input
+                # keys and values only (the last layer of a cross-encoder)
+                self.kv_w, self.kv_b = pack_linear(layer.qkv.weight[H:], layer.qkv.bias[H:], False)
+                self.kv_w_fr, _ = pack_linear(layer.qkv.weight[H:], layer.qkv.bias[H:], True)
                 self.stream = pack_tail_stream(layer.out.weight, layer.up.weight, layer.down.weight)
                 self.tables = tail_tables(layer.out.bias, layer.ln1.weight, layer.ln1.bias, layer.down.bias,
                                           layer.ln2.weight, layer.ln2.bias, layer.up.bias)

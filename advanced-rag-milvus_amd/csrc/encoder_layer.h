@@ -85,6 +85,7 @@ __device__ inline float el_gelu_tanh(float v) {
 }
 __device__ inline float el_gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.7071067811865476f)); }
 
+
 // This lane's B fragments of 16 rows x (32 KS) features, fragment order or row-major (-> accumulator k order either way
 // when `acc_order`, natural k order otherwise; fragment-order buffers are always in accumulator k order).
 template <int KS>
@@ -162,25 +163,29 @@ struct ElStream {
     template <class F, class S>
     __device__ inline void consume(unsigned addr, F&& f, S&& side) {
         static_assert(L == SP / 4, "one refill piece per group of four");
-        chunk_t a[2][4];
+        constexpr int NGR = SP / 4;
+        chunk_t a[3][4];   // groups gi + 1 and gi + 2 are requested before group gi is used
         if (EL_ABLATE & 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[0][j] = a[1][j] = (chunk_t){addr, addr + j, 0x3c003c00u, 0x38003800u};
+            for (int j = 0; j < 4; ++j) a[0][j] = a[1][j] = a[2][j] = (chunk_t){addr, addr + j, 0x3c003c00u, 0x38003800u};
         } else {
             el_ds_read4(a[0], addr);
+            if (NGR > 1) el_ds_read4(a[1], addr + 4096);
         }
 #pragma unroll
-        for (int gi = 0; gi < SP / 4; ++gi) {
+        for (int gi = 0; gi < NGR; ++gi) {
             if (!(EL_ABLATE & 2)) {
-                if (gi + 1 < SP / 4) {
-                    el_ds_read4(a[(gi + 1) & 1], addr + (gi + 1) * 4096);
-                    el_wait_lgkm<4>(a[gi & 1]);
+                if (gi + 2 < NGR) {
+                    el_ds_read4(a[(gi + 2) % 3], addr + (gi + 2) * 4096);
+                    el_wait_lgkm<8>(a[gi % 3]);
+                } else if (gi + 1 < NGR) {
+                    el_wait_lgkm<4>(a[gi % 3]);
                 } else {
-                    el_wait_lgkm<0>(a[gi & 1]);
+                    el_wait_lgkm<0>(a[gi % 3]);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) f(gi * 4 + j, el_as_half8(a[gi & 1][j]));
+            for (int j = 0; j < 4; ++j) f(gi * 4 + j, el_as_half8(a[gi % 3][j]));
             issue_piece(gi);
             side(gi);
         }
@@ -193,9 +198,11 @@ struct ElStream {
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
-// out[M][N] (row stride out_stride) = x[M][K] W^T + bias, K = 32 KS, N a multiple of 32.  W packed naturally:
-// piece (t, s) = W[16 t .. 16 t + 15][32 s .. 32 s + 31] in A-fragment order, pieces ordered [t][s]; a stage = two output
-// tiles.  bias: fp32 [N].
+// out[M][N] (row stride out_stride) = x[M][K] W^T + bias, K = 32 KS, N a multiple of 32.  Pieces ordered [t][s]; a stage =
+// two output tiles = 32 output features.  The ROWS of W are packed in "store order": row r of tile 2 so + u is output
+// feature 32 so + 8 (r >> 2) + 4 u + (r & 3), so that the eight results a lane holds after a stage (rows 4 g .. 4 g + 3 of
+// both tiles) are eight CONSECUTIVE features 32 so + 8 g .. + 7 of its row: one 16-byte store per token tile and stage
+// instead of two 8-byte ones 32 bytes apart.  bias: fp32 [N] in the same order ([so][u][r]).
 struct LinearArgs {
     const _Float16* x;
     const chunk_t* w;       // natural k order for row-major x, accumulator k order for fragment-order x
@@ -254,13 +261,10 @@ __global__ __launch_bounds__(64 * kElWaves, 1) void linear_rows_kernel(LinearArg
         for (int tt = 0; tt < TT; ++tt) {
             const int64_t row = tok0 + 16 * tt + col;
             if (row < p.M) {
+                half8_t w;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    half4_t w;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) w[r] = (_Float16)acc[u][tt][r];
-                    *reinterpret_cast<half4_t*>(p.out + row * p.out_stride + 32 * so + 16 * u + 4 * g) = w;
-                }
+                for (int j = 0; j < 8; ++j) w[j] = (_Float16)acc[j >> 2][tt][j & 3];
+                *reinterpret_cast<half8_t*>(p.out + row * p.out_stride + 32 * so + 8 * g) = w;
             }
         }
     }

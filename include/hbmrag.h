@@ -361,6 +361,8 @@ HR_API int hr_attention_rows_f16_dev(const void* d_q, int64_t q_seq_stride, int6
  *
  * hr_linear_rows_f16_dev:  d_out[r][0..N) (row-major, row stride out_stride halves) = x[r][0..K) W^T + bias.  d_x: row-major
  *   [rows][K] (x_fr = 0: d_w_packed pieces [N/16][K/32] in natural k order) or FR (x_fr = 1: accumulator k order).
+ *   The rows of W (and d_bias) are packed in STORE ORDER: packed row 32 so + 16 u + r = output feature
+ *   32 so + 8 (r >> 2) + 4 u + (r & 3), which makes a lane's eight results of a stage eight consecutive features of its row.
  *   N a multiple of 32 (<= 4096); K = 384 (HR_ELIMIT otherwise: callers keep their GEMM).
  * hr_attention_fr_f16_dev: hr_attention_f16_dev with its output in FR ([rows = n_seq * T][heads * head_dim]).
  * hr_encoder_tail_f16_dev: out = LN2(x1 + W_down gelu(W_up x1 + b_up) + b_down), x1 = LN1(x + W_out attn + b_out)
