@@ -274,6 +274,7 @@ def test_g11_retrieve_under_mmr_profiles_on_device_matches_reference(gpu, long_t
     from advanced_rag.embedding_cache import initialize_caches
     g, X, csr, Q, SQ = g5_data.inputs()
     runs = gold("g11_mmr.json")["retrieve"]
+    flips = []
     for with_sparse in (True, False):
         mgr = _mmr_manager(dtype, X, csr, with_sparse)
         try:
@@ -282,13 +283,42 @@ def test_g11_retrieve_under_mmr_profiles_on_device_matches_reference(gpu, long_t
                 mgr.embedding_generator = _KeyedGen(Q, SQ, fixed=run["query"])
                 retr = HybridRetriever(mgr, RetrievalConfig(top_k=20))
                 out = asyncio.run(retr.retrieve("plain statement", profile_hint=run["profile_hint"]))
-                assert [o["id"] for o in out] == run["ids"], (with_sparse, run["profile_hint"], run["query"])
-                assert [float(o["score"]).hex() for o in out] == run["scores"]
-                assert [sorted(o["retrieval_methods"]) for o in out] == run["methods"]
+                want = (run["ids"], run["scores"], run["methods"])
+                if dtype == "float16" and ([o["id"] for o in out] != run["ids"] or [float(o["score"]).hex() for o in out] != run["scores"]):
+                    # rows rounded to fp16 move cosine scores by ~1e-4 relative: deep in a 60- / 80-long list two neighbours
+                    # may swap against the fp32 reference (k' = 40 lists never did, test_g5_..._fp16) — which shows as other ids, or,
+                    # when only one of the two rows survives the MMR cut, as another fused score of that row.  Such a run is held
+                    # against the oracle chain on the SAME fp16 rows instead (ids, fused scores, methods: exact), and the
+                    # swap must be explained by an fp32 score gap below the rounding.
+                    import oracle
+                    X16 = X.astype(np.float16)
+                    kp, top_k = 2 * run["top_k"], run["top_k"]
+                    di, _ = oracle.dense_search(X16, Q[run["query"]:run["query"] + 1], kp, oracle.COSINE)
+                    sl = ()
+                    if with_sparse:
+                        si, _ = oracle.sparse_search(csr[0], csr[1], csr[2], [SQ[run["query"]]], kp, 0.2)
+                        sl = si[0][si[0] >= 0]
+                    ids, scores, methods = oracle.rrf(di[0], sl, (), 0.7, 0.3, 0.2, 60)
+                    sel = (oracle.mmr(ids, [float(x) for x in scores], [g5_data.mmr_content(int(r)) for r in ids], top_k, run["mmr_lambda"])
+                           if run["enable_mmr"] else list(range(len(ids))))[:top_k]
+                    want = ([g5_data.row_id(int(ids[i])) for i in sel], [float(scores[i]).hex() for i in sel],
+                            [method_names(methods[i]) for i in sel])
+                    Xn = X / np.linalg.norm(X, axis=1, keepdims=True)
+                    s32 = Xn @ (Q[run["query"]] / np.linalg.norm(Q[run["query"]]))
+                    d32 = np.lexsort((np.arange(len(s32)), -s32))[:kp]
+                    gaps = [abs(float(s32[x]) - float(s32[y])) for x, y in zip(d32, di[0]) if x != y]   # rows that changed places
+                    assert gaps and max(gaps) < 5e-4, gaps
+                    flips.append((with_sparse, run["profile_hint"], run["query"]))
+                assert [o["id"] for o in out] == want[0], (with_sparse, run["profile_hint"], run["query"])
+                assert [float(o["score"]).hex() for o in out] == want[1]
+                assert [sorted(o["retrieval_methods"]) for o in out] == want[2]
                 assert out[0]["metadata"]["retrieval_profile"] == run["profile"]
                 assert (retr.config.enable_mmr, retr.config.mmr_lambda, retr.config.top_k) == (run["enable_mmr"], run["mmr_lambda"], run["top_k"])
         finally:
             asyncio.run(mgr.close())
+    print(f"g11 {dtype}: {len(runs) - len(flips)}/{len(runs)} runs identical to the fp32 reference; runs with a near-tie swap: {flips}")
+    assert dtype == "float16" or not flips
+    assert len(flips) <= len(runs) // 3
 
 
 def test_g12_pipeline_retrieve_on_device_matches_reference(gpu, long_timeout):
@@ -302,7 +332,9 @@ def test_g12_pipeline_retrieve_on_device_matches_reference(gpu, long_timeout):
     cases = gold("g12_pipeline.json")["cases"]
     for c in cases:
         initialize_caches()
-        pipe = AdvancedRAGPipeline(connect_to_milvus=False,
+        # (connect_to_milvus=True is what creates the collections here — in HBM; the reference's run used
+        # connect_to_milvus=False and put fake collections into the manager)
+        pipe = AdvancedRAGPipeline(connect_to_milvus=True,
                                    config=PipelineConfig(enable_audit_logging=False, rerank_top_k=c["pipeline_rerank_top_k"],
                                                          enable_reranking=c["enable_reranking"], top_k=c["top_k"]),
                                    semantic_dim=X.shape[1], sparse_dim=g5_data.SPARSE_DIM, dtype="float32", enable_domain=False)
