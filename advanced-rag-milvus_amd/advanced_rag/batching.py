@@ -76,7 +76,8 @@ class SearchCoalescer:
         # broadcast + ONE gather for all the dense and sparse searches that share (top_k, filter, drop ratio)
         self.collective = hasattr(getattr(manager, "_main", None), "round")
         self.stats = {"rounds": 0, "requests": 0, "dense_launches": 0, "sparse_launches": 0, "fuse_launches": 0,
-                      "hybrid_launches": 0, "max_batch_seen": 0, "redone_unproven": 0, "busy_s": 0.0}
+                      "hybrid_launches": 0, "encode_launches": 0, "encoded_texts": 0, "max_batch_seen": 0, "redone_unproven": 0,
+                      "busy_s": 0.0}
         self._engines: Dict[Tuple, Any] = {}   # hybrid engines per (top_k, rrf_k)
         self._inflight: List[_Request] = []    # the requests of the round in progress (failed as a whole if the worker dies)
 
@@ -160,7 +161,7 @@ class SearchCoalescer:
         dev = torch.device("cuda", self.mgr.device)
         # one stream per kind of work: the dense and the sparse searches of a round run side by side (a lone retrieve()
         # overlaps its two scans, as its two worker threads did before the front existed)
-        streams = {k: torch.cuda.Stream(dev) for k in ("dense", "sparse", "fuse", "hybrid")}
+        streams = {k: torch.cuda.Stream(dev) for k in ("dense", "sparse", "fuse", "hybrid", "encode")}
         while True:
             reqs = self._collect()
             if reqs is None:
@@ -270,6 +271,8 @@ class SearchCoalescer:
                     _deliver(r.future, self.mgr._fuse_rows_blocking(r.payload, key))
                 elif kind == "hybrid":
                     _deliver(r.future, None)   # the caller falls back to two searches + a fusion
+                elif kind == "encode":
+                    _deliver(r.future, self.mgr.embedding_generator.encode_to_device([r.payload[1]])[0])
                 else:
                     coll_name, top_k, expr, params_key = key
                     _deliver(r.future, self.mgr._search_lists_blocking(r.payload, coll_name, top_k, expr, dict(params_key)))
@@ -394,6 +397,27 @@ class SearchCoalescer:
                 continue
             n = int(fn[i])
             _deliver(r.future, (fi[i, :n].copy(), fs[i, :n].copy(), fm[i, :n].copy(), orig[i, :n].copy()))
+
+    # ------------------------------------------------------------------ query encoder
+    def _enqueue_encode(self, torch, dev, stream, key, chunk):
+        """The query texts of a round's cache misses in ONE forward of the sentence encoder (the reference embeds each
+        request alone, indexing.py:601-627; its batch form loops per text, :580-587): payload = (cache key, text).  The rows
+        go into the manager's device-resident embedding table (when it has one) and are handed to the callers as device
+        tensors — the search round that follows reads them in place, no host hop."""
+        gen = self.mgr.embedding_generator
+        texts: Dict[str, str] = {}
+        for r in chunk:
+            texts.setdefault(r.payload[0], r.payload[1])
+        vecs = gen.encode_to_device(list(texts.values()), batch_size=len(texts))
+        table = getattr(self.mgr, "_dev_cache", None)
+        rows = {k: (table.store(k, vecs[i]) if table is not None else vecs[i]) for i, k in enumerate(texts)}
+        self.stats["encode_launches"] += 1
+        self.stats["encoded_texts"] += len(texts)
+        return {"rows": rows, "keep": vecs}
+
+    def _scatter_encode(self, key, chunk, st):
+        for r in chunk:
+            _deliver(r.future, st["rows"][r.payload[0]])
 
     # ------------------------------------------------------------------ fuse
     def _enqueue_fuse(self, torch, dev, stream, key, chunk):

@@ -13,6 +13,7 @@ first 16 bytes equal the literal's come back in an "undecided" mask and are sett
 """
 from __future__ import annotations
 
+import threading
 from typing import Any, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -50,6 +51,10 @@ class DeviceFilters:
         self.device = int(device)
         self._dev: Dict[str, Tuple[Any, int]] = {}   # column -> (device tensor with spare capacity, rows uploaded)
         self.stats = {"evaluations": 0, "undecided_rows": 0, "uploaded_bytes": 0}
+        # one evaluation at a time: the column tensors are owned by `_dev` alone, so a second thread that re-uploads a
+        # column (the dense and the sparse search of an uncoalesced retrieve() evaluate a new expression concurrently)
+        # would free the tensor the first thread's kernel is about to read
+        self._lock = threading.RLock()
 
     # ------------------------------------------------------------------ columns in HBM
     def _tensor(self, name: str, host_rows, n: int, width: int = 1):
@@ -122,6 +127,10 @@ class DeviceFilters:
     # ------------------------------------------------------------------ evaluation
     def evaluate(self, expr: Optional[str], n_rows: int, deleted: Optional[np.ndarray] = None, stream=None):
         """-> (uint8 CUDA tensor of mask_bytes(n_rows) packed bits, rows kept).  expr None = tombstones only."""
+        with self._lock:
+            return self._evaluate_locked(expr, n_rows, deleted, stream)
+
+    def _evaluate_locked(self, expr, n_rows, deleted, stream):
         import torch
         dev = torch.device("cuda", self.device)
         terms, string_terms = self._terms(expr, n_rows) if expr else ([], [])

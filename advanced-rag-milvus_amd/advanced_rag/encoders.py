@@ -379,12 +379,16 @@ class SentenceEncoder(_Base):
         self.domain_dim = domain_dim or self.dim
 
     @torch.inference_mode()
-    def encode_to_device(self, texts: Sequence[str]) -> torch.Tensor:
-        """float32 [n, dim] tensor on the encoder's device (feeds hr_add_dense_raw_dev / search without a host hop)."""
+    def encode_to_device(self, texts: Sequence[str], batch_size: Optional[int] = None) -> torch.Tensor:
+        """float32 [n, dim] tensor on the encoder's device (feeds hr_add_dense_raw_dev / search without a host hop).
+        batch_size overrides the encoder's own (the batching front encodes the queries of a round in ONE forward)."""
         out = []
-        for i in range(0, len(texts), self.batch_size):
-            ids, types, mask = self.tokenizer.batch(texts[i: i + self.batch_size], device=self.device)
+        step = batch_size or self.batch_size
+        self.forwards = getattr(self, "forwards", 0)
+        for i in range(0, len(texts), step):
+            ids, types, mask = self.tokenizer.batch(texts[i: i + step], device=self.device)
             out.append(self.module(ids, types, mask))
+            self.forwards += 1
         return torch.cat(out) if out else torch.zeros((0, self.dim), device=self.device)
 
     @torch.inference_mode()

@@ -24,6 +24,7 @@ plus index_chunks / get_collection_stats / delete_by_filter / close.
 from __future__ import annotations
 
 import asyncio
+import threading
 import logging
 import os
 from concurrent.futures import ThreadPoolExecutor
@@ -141,6 +142,7 @@ class MilvusIndexManager:
         self.coalesce = bool(coalesce)
         self._front = None
         self._dev_masks: Dict[Any, Any] = {}   # (expr, rows, delete epoch, kind) -> packed row mask in HBM
+        self._mask_lock = threading.RLock()
         if connect:
             self._connect()
             self._initialize_collections()
@@ -248,11 +250,12 @@ class MilvusIndexManager:
         if not expr and not dead:
             return None
         key = ("global", expr, n, self._delete_epoch)
-        hit = self._dev_masks.get(key)
-        if hit is None:
-            if len(self._dev_masks) >= 32:
-                self._dev_masks.pop(next(iter(self._dev_masks)))
-            hit = self._dev_masks[key] = self._filters_on_device().evaluate(expr, n, self._deleted if dead else None)[0]
+        with self._mask_lock:   # searches of one request run in different threads and ask for the same new mask at once
+            hit = self._dev_masks.get(key)
+            if hit is None:
+                if len(self._dev_masks) >= 32:
+                    self._dev_masks.pop(next(iter(self._dev_masks)))
+                hit = self._dev_masks[key] = self._filters_on_device().evaluate(expr, n, self._deleted if dead else None)[0]
         return hit
 
     def _row_mask(self, expr: Optional[str]) -> Optional[np.ndarray]:
@@ -840,15 +843,46 @@ class MilvusIndexManager:
         return self._dev_cache.store(key, fresh)
 
     async def _generate_semantic_embedding(self, text: str):
+        gen = self.embedding_generator
         if self._dev_cache_slots > 0 and self._main is not None and not (
-                self.embedding_generator is not None and asyncio.iscoroutinefunction(self.embedding_generator.encode_semantic)):
+                gen is not None and asyncio.iscoroutinefunction(gen.encode_semantic)):
+            from .embedding_cache import DeviceEmbeddingTable, EmbeddingCache
+            if self._dev_cache is None:
+                self._dev_cache = DeviceEmbeddingTable(self._dev_cache_slots, self.semantic_dim, f"cuda:{self.device}")
+                self.device_cache_stats = {"hits": 0, "misses": 0}
+            key = EmbeddingCache._materialize_key(text)
+            hit = self._dev_cache.lookup(key)
+            if hit is not None:          # a hit is a dictionary lookup: no executor hop, no task
+                self.device_cache_stats["hits"] += 1
+                return hit
+            front = self._encode_front(gen)
+            if front is not None:        # the misses of a round share ONE encoder forward (batching.py::_enqueue_encode)
+                self.device_cache_stats["misses"] += 1
+                return await asyncio.wrap_future(front.submit("encode", ("encode",), (key, text)))
             return await asyncio.get_event_loop().run_in_executor(self.embedding_executor, self._device_query_embedding, text)
+        front = self._encode_front(gen)
+        if front is not None:
+            from .embedding_cache import EmbeddingCache
+            key = EmbeddingCache._materialize_key(text)
+
+            async def compute_batched() -> np.ndarray:   # the host cache holds host arrays (reference indexing.py:601-627)
+                row = await asyncio.wrap_future(front.submit("encode", ("encode",), (key, text)))
+                return await asyncio.get_event_loop().run_in_executor(self.embedding_executor, lambda: row.cpu().numpy())
+            return await get_semantic_cache().get_or_compute(text, compute_batched)
 
         async def compute() -> np.ndarray:
             if self.embedding_generator:
                 return await self._run_encoder(self.embedding_generator.encode_semantic, text)
             return np.random.randn(self.semantic_dim).astype(np.float32)
         return await get_semantic_cache().get_or_compute(text, compute)
+
+    def _encode_front(self, gen):
+        """The batching front when it can encode queries for this manager (a generator with `encode_to_device` on a
+        single-shard, single-process manager), else None."""
+        if gen is None or not hasattr(gen, "encode_to_device") or not self.coalesce or "semantic_index" not in self.collections:
+            return None
+        front = self._coalescer(self.collections["semantic_index"])
+        return None if front is None or front.collective else front
 
     async def _generate_sparse_embedding(self, text: str, role: str = "query"):
         gen = self.embedding_generator

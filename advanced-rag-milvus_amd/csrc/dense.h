@@ -166,7 +166,9 @@ __global__ __launch_bounds__(512) void dense_scan_kernel(
     auto prefetch = [&](int slot) {
         // Unconditional load (no control flow around VMEM, so the compiler keeps
         // counted vmcnt waits): past the wave's last group re-read its first one.
-        const int64_t grp = pf_group < n_groups ? pf_group : wave;
+        // (a wave WITHOUT any group — the last block may hold up to three — re-reads group 0: `wave` itself is past the end of
+        // the shard there, and with 48 KiB super-groups at D = 384 that read crossed into an unmapped page: round 4)
+        const int64_t grp = pf_group < n_groups ? pf_group : (wave < n_groups ? wave : 0);
         const int64_t rb = grp * kRowBlocksPerSuper + pf_pair * RS;
 #pragma unroll
         for (int s = 0; s < RS; ++s)

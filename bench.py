@@ -440,12 +440,32 @@ def main():
             b["ce_ids"] = ids[:B]
             b["ce_scores"] = sc[:B]
 
+        def forward_alone(reps=5):
+            """ms per forward of the same pairs on an otherwise idle chip (the figure in the pipeline shares the chip with the
+            scans of the next batches)."""
+            if not ce_pairs:
+                return 0.0
+            toks = (1000 + (pos * 104729 + qslot * 31 + torch.arange(args.top_k, device=dev)[None, :, None] * 7919) % (vocab - 1000)).view(ce_pairs, T)
+            toks[:, 0] = 101
+            torch.cuda.synchronize()
+            with torch.inference_mode():
+                for _ in range(2):
+                    ce.module(toks, types, mask)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    ce.module(toks, types, mask)
+                e1.record()
+                e1.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        cross_encode.alone = forward_alone
         return cross_encode, events, ce_pairs, ce
 
     if args.rerank == "cross-encoder":
         T = args.ce_seq_len
         cross_encode, ce_events, ce_pairs, ce = make_cross_encoder(T)
-        ce_note = (f"+ cross-encoder rerank {args.top_k}->{cfg.rerank_top_k}: random-init MiniLM-L6-H384 (PyTorch-ROCm, fp16), "
+        ce_note = (f"+ cross-encoder rerank {args.top_k}->{cfg.rerank_top_k}: random-init MiniLM-L6-H384 (hand-written HIP layer kernels, fp16), "
                    f"{B * args.top_k} pairs x {T} tokens per step" + (f", the queries split over the {world} ranks" if world > 1 else ""))
         if n_fly > 1:
             eng.post_hook = cross_encode
@@ -544,14 +564,19 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             ph = h.kernel_ms()
+            eng.synchronize()
+            alone_ms = hook.alone()
             config4_full[f"seq_len_{T}"] = {
                 "value": B * k_full / el, "unit": "queries/s", "ms_per_step": el / k_full * 1e3, "steps": k_full, "warmup": w_full,
-                "cross_encoder": ce_report(ce_m, evs, pairs, T),
+                "cross_encoder": ce_report(ce_m, evs, pairs, T, alone_ms),
                 "dense_scan_ms": round(ph["dense_scan"][0], 4), "sparse_scan_ms": round(ph["sparse_scan"][0], 4)}
             eng.post_hook = None
         eng.synchronize()
-        config4_full["note"] = ("hybrid dense+sparse -> RRF -> cross-encoder rerank 20 -> 5: random-init MiniLM-L6-H384 (PyTorch-ROCm fp16 "
-                                "GEMMs + HIP elementwise / attention kernels), synthetic token ids; the forward runs on the finishing stream")
+        config4_full["note"] = ("hybrid dense+sparse -> RRF -> cross-encoder rerank 20 -> 5: random-init MiniLM-L6-H384, fp16, every full layer "
+                                "as three hand-written HIP launches (QKV projection, attention, output projection + LayerNorm + FFN + "
+                                "LayerNorm: csrc/encoder_layer.h, attention.h), the last layer's token-0 rows and the head through "
+                                "PyTorch-ROCm; synthetic token ids; the forward runs on the finishing stream, i.e. `frac` is measured "
+                                "while the scans of the next batches share the chip — `frac_alone` is the same forward on an idle chip")
 
     # every rank merges the same gathered lists, so every rank must hold the same fused answer for the last batch
     ranks_agree = None
@@ -710,8 +735,8 @@ def bench_ingest(args):
         return {"id": f"doc{i}", "text": " ".join(sents), "metadata": {"source": "bench"}}
 
     docs = [make_doc(i) for i in range(args.ingest_docs)]
-    cfg = EncoderConfig(hidden=args.dim, layers=12, intermediate=4 * args.dim, heads=12) if args.dim >= 768 else \
-        EncoderConfig(hidden=args.dim)
+    cfg = EncoderConfig(hidden=args.dim, layers=12, intermediate=4 * args.dim, heads=args.dim // 64) if args.dim >= 768 else \
+        EncoderConfig(hidden=args.dim)   # bge-base / bge-large shapes: heads of 64 (12 x 64 = 768, 16 x 64 = 1024)
     bm25 = BM25SparseEncoder(sparse_dim=SPARSE_DIM).fit(d["text"] for d in docs)
     enc = SentenceEncoder(cfg, device=dev, sparse_encoder=bm25, max_len=256, batch_size=128)
 
@@ -755,17 +780,47 @@ def bench_ingest(args):
                      "rows_in_shard": rows, "encoder_ms": tm["encode"], "append_ms": tm["append"], "flush_ms": tm["flush"],
                      "host_pipeline_ms": wall * 1e3 - tm["encode"] - tm["append"] - tm["flush"]}
         asyncio.run(pipe.close())
+    # the sentence encoder's forward by itself (reference hook: indexing.py:610-620 encode_semantic / :580-587 the batch form):
+    # 1 024 sequences x 512 tokens of synthetic ids, HIP events around the forwards, arithmetic = per token and layer
+    # 24 H^2 (projections + FFN) + 4 T H (attention products)
+    T_enc, n_enc = 512, 1024
+    big = SentenceEncoder(cfg, device=dev, max_len=512, batch_size=128)
+    ids = torch.randint(1000, 30000, (n_enc, T_enc), device=dev)
+    ids[:, 0] = 101
+    types = torch.zeros((n_enc, T_enc), dtype=torch.long, device=dev)
+    mask = torch.ones((n_enc, T_enc), dtype=torch.bool, device=dev)
+    with torch.inference_mode():
+        for _ in range(2):
+            big.module(ids, types, mask)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            big.module(ids, types, mask)
+        e1.record()
+        e1.synchronize()
+    enc_ms = e0.elapsed_time(e1) / 5
+    Hd, Ld = cfg.hidden, cfg.layers
+    enc_flop = n_enc * Ld * (2 * T_enc * (4 * Hd * Hd + 2 * Hd * cfg.intermediate) + 4 * T_enc * T_enc * Hd)
+    enc_tf = enc_flop / (enc_ms * 1e-3) / 1e12
+    sentence_encoder = {"model": f"random-init BERT hidden {Hd} x {Ld} layers, {cfg.heads} heads x {Hd // cfg.heads}, fp16",
+                        "sequences": n_enc, "seq_len": T_enc, "forward_ms": enc_ms, "flop_per_forward": enc_flop,
+                        "achieved": enc_tf, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": enc_tf / MFMA_F16_PEAK_TFLOPS,
+                        "tokens_per_s": n_enc * T_enc / (enc_ms * 1e-3),
+                        "kernels": ("hand-written layer kernels (encoder_layer.h) + HIP attention" if all(
+                            getattr(l, "_fused_ok")(torch.empty((1, T_enc, Hd), dtype=torch.float16, device=dev), torch.ones(1, dtype=torch.int32, device=dev), Hd // cfg.heads, T_enc)
+                            for l in big.module.encoder.layers) else
+                            "hipBLASLt GEMMs (bias + GELU epilogue) + HIP attention (head dim 64: attention.h) + HIP add + LayerNorm")}
     print(json.dumps({"metric": "ingest_docs_per_sec", "value": out["device_to_device"]["docs_per_s"], "unit": "docs/s",
                       "n_gpus": 1, "data": "synthetic", "dtype": "f16",
                       "config": {"workload": f"{len(docs)} documents x ~512 tokens -> AdvancedRAGPipeline.ingest_documents, "
                                              f"SentenceEncoder random-init hidden {args.dim} (PyTorch-ROCm fp16) + BM25, "
                                              f"{args.ingest_batch} documents per call, fp16 shard"},
-                      "paths": out,
+                      "paths": out, "sentence_encoder": sentence_encoder,
                       "note": "encoder_ms includes the host-side sparse (BM25) payloads of the call; host_pipeline_ms = "
                               "diagnostics + chunking + enrichment in Python"}))
 
 
-def ce_report(ce, events, pairs: int, T: int):
+def ce_report(ce, events, pairs: int, T: int, alone_ms: float = 0.0):
     """Forward pass of the cross-encoder leg (BASELINE config 4's rerank 20 -> 5; north_star assigns it to PyTorch-ROCm):
     device ms per step from events around the forward, its arithmetic (per token and layer 24 H^2 for the projections and
     the FFN + 4 T H for the attention products) and the share of the fp16 MFMA peak."""
@@ -774,8 +829,9 @@ def ce_report(ce, events, pairs: int, T: int):
     flops = pairs * ce.flops_per_pair(T)   # the arithmetic the forward EXECUTES: last layer = keys / values + token 0 (encoders.py)
     ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else 0.0
     tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    return {"model": f"random-init MiniLM-L{L}-H{H} (PyTorch-ROCm, fp16)", "pairs_per_step": pairs, "seq_len": T,
-            "forward_ms_per_step": ms, "flop_per_step": flops,
+    alone = {"forward_alone_ms": alone_ms, "frac_alone": flops / (alone_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS} if alone_ms > 0 else {}
+    return {"model": f"random-init MiniLM-L{L}-H{H} (hand-written HIP layer kernels, fp16)", "pairs_per_step": pairs, "seq_len": T,
+            "forward_ms_per_step": ms, "flop_per_step": flops, **alone,
             "flop_per_step_if_every_layer_ran_over_every_token": pairs * ce.flops_per_pair(T, executed=False),
             "achieved": tf, "peak": MFMA_F16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TFLOPS, "forwards_timed": len(events)}

@@ -342,3 +342,78 @@ def test_requests_with_different_fusion_weights_share_one_round(gpu, long_timeou
             assert [float(s) for _, s, _ in b[i]] == [v for _, v in top]
     finally:
         asyncio.run(mgr.close())
+
+
+@pytest.mark.parametrize("device_cache", [256, 0])
+def test_concurrent_retrieves_share_encoder_forwards(gpu, long_timeout, device_cache):
+    """The query encoder inside retrieve(): 64 concurrent AdvancedRAGPipeline.retrieve() calls with a SentenceEncoder as the
+    embedding generator encode their cache misses in ONE forward per round of the front (the reference embeds each request
+    alone, indexing.py:601-627), the rows stay on the device (device-resident table) or go once to the host cache, and
+    every caller gets what a sequential caller gets with the same embedding."""
+    from advanced_rag import AdvancedRAGPipeline, PipelineConfig
+    from advanced_rag.embedding_cache import initialize_caches
+    from advanced_rag.encoders import EncoderConfig, SentenceEncoder
+    rng = np.random.default_rng(17)
+    n, d, V, nq = 30000, 384, 1000, 64
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    idx = np.sort(np.argpartition(rng.random((n, V)), 9, axis=1)[:, :10], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * 10)).astype(np.float32)
+    enc = SentenceEncoder(EncoderConfig(), device="cuda:0", max_len=64, batch_size=16)
+    texts = [f"question number {i} about topic {i % 7} and the matter of item {i * 31 % 101}" for i in range(nq)]
+
+    class Gen:
+        """The encoder for the dense side; a fixed sparse query per text (BM25 is not what is under test)."""
+        encode_to_device = enc.encode_to_device
+        encode_semantic = enc.encode_semantic
+        encode_semantic_batch = enc.encode_semantic_batch
+
+        def encode_sparse(self, text):
+            r = np.random.default_rng(abs(hash(text)) % (2 ** 32))
+            qi = np.sort(r.choice(V, 12, replace=False))
+            return {"indices": qi.tolist(), "values": np.abs(r.standard_normal(12)).tolist()}
+
+        def encode_domain(self, text, domain=None):
+            return np.zeros(8, np.float32)
+
+    initialize_caches()
+    pipe = AdvancedRAGPipeline(config=PipelineConfig(enable_audit_logging=False), semantic_dim=d, sparse_dim=V, dtype="float16",
+                               enable_domain=False, device_embedding_cache=device_cache)
+    mgr = pipe.index_manager
+    mgr.add_rows(X, (np.arange(n + 1, dtype=np.int64) * 10, idx, val))
+    mgr.finalize()
+    mgr.embedding_generator = Gen()
+    pipe.retriever.config.enable_learned_ranker = True
+
+    def strip(res):
+        return [(r.chunk_id, float(r.score).hex(), r.retrieval_method) for r in res]
+
+    async def concurrent():
+        return await asyncio.gather(*[pipe.retrieve(t, context={"retrieval_profile": "default"}) for t in texts])
+
+    async def sequential():
+        return [await pipe.retrieve(t, context={"retrieval_profile": "default"}) for t in texts]
+
+    import contextlib, io
+    try:
+        f0 = getattr(enc, "forwards", 0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            conc = asyncio.run(concurrent())
+        st = mgr._front.stats
+        forwards = enc.forwards - f0
+        assert st["encoded_texts"] == nq and forwards == st["encode_launches"], (st, forwards)
+        assert forwards <= 4, forwards                     # one forward per round of the front, not one per request
+        assert all(len(r) == 5 for r, _ in conc)
+        with contextlib.redirect_stdout(io.StringIO()):
+            seq = asyncio.run(sequential())                # cache hits: the same embeddings, one request at a time
+        assert enc.forwards - f0 == forwards               # nothing was encoded again
+        assert [strip(r) for r, _ in conc] == [strip(r) for r, _ in seq]
+        if device_cache:
+            assert mgr.device_cache_stats["misses"] == nq and mgr.device_cache_stats["hits"] >= nq
+        # the batched forward gives the embedding a lone forward gives (up to fp16 padding effects)
+        lone = enc.encode_to_device([texts[3]])[0]
+        from advanced_rag.embedding_cache import EmbeddingCache
+        got = (mgr._dev_cache.lookup(EmbeddingCache._materialize_key(texts[3])) if device_cache
+               else torch.from_numpy(asyncio.run(mgr._generate_semantic_embedding(texts[3]))).cuda())
+        assert torch.allclose(got, lone, atol=3e-3), (got - lone).abs().max()
+    finally:
+        asyncio.run(pipe.close())

@@ -225,3 +225,24 @@ def test_config5_shape_d1024_fp16(gpu, n, B):
         assert np.array_equal(ids[pick], oids)
         assert np.array_equal(_bits(sc[pick]), _bits(osc))
     h.close()
+
+
+@pytest.mark.parametrize("n", [30016, 30000, 4 * 64 + 16])
+def test_idle_scan_waves_stay_inside_the_shard(gpu, n):
+    """A scan block's waves beyond the last super-group used to prefetch 'their own' group — past the end of the tiles.  At
+    D = 384 (48 KiB per super-group) and 469 super-groups that read crossed into an unmapped page and the GPU faulted
+    (found in round 4 with a 30 000 x 384 shard behind a sentence encoder); the waves now re-read group 0.  The search
+    itself must (still) equal the oracle."""
+    import oracle
+    from advanced_rag import _native as nat
+    rng = np.random.default_rng(n)
+    X = rng.standard_normal((n, 384)).astype(np.float16)
+    h = nat.ShardHandle(384, nat.HR_F16, nat.HR_METRIC_COSINE, 0)
+    h.add_dense(X)
+    h.finalize()
+    Q = rng.standard_normal((3, 384)).astype(np.float32)
+    for b in (1, 3):
+        ids, sc = h.search_dense(Q[:b], 40)
+        oi, osc = oracle.dense_search(X, Q[:b], 40, oracle.COSINE)
+        assert np.array_equal(ids, oi) and np.array_equal(sc.view(np.uint32), osc.view(np.uint32))
+    h.close()
