@@ -50,6 +50,40 @@ def _fail(fut: Future, exc: BaseException) -> None:
         pass
 
 
+def _set_many(items) -> None:
+    """On the event loop: the answers of one round, in one callback."""
+    for fut, ok, value in items:
+        if not fut.done():          # a caller that timed out or was cancelled is simply skipped
+            if ok:
+                fut.set_result(value)
+            else:
+                fut.set_exception(value)
+
+
+class _LoopFuture:
+    """What a coroutine's request carries instead of a concurrent Future: the asyncio future it awaits.  Answers are
+    collected in the front's outbox and handed to the loop with ONE call_soon_threadsafe per round (asyncio.wrap_future
+    costs a concurrent future, a chained callback and a loop wake-up per request)."""
+    __slots__ = ("loop", "afut", "outbox", "_done")
+
+    def __init__(self, loop, afut, outbox):
+        self.loop, self.afut, self.outbox, self._done = loop, afut, outbox, False
+
+    def done(self) -> bool:
+        return self._done or self.afut.cancelled()     # a benign cross-thread read: worst case one unread answer
+
+    def set_running_or_notify_cancel(self) -> bool:
+        return not self.afut.cancelled()
+
+    def set_result(self, value) -> None:
+        self._done = True
+        self.outbox.setdefault(self.loop, []).append((self.afut, True, value))
+
+    def set_exception(self, exc) -> None:
+        self._done = True
+        self.outbox.setdefault(self.loop, []).append((self.afut, False, exc))
+
+
 @dataclass
 class _Request:
     kind: str                 # "dense" | "sparse" | "fuse"
@@ -80,6 +114,7 @@ class SearchCoalescer:
                       "busy_s": 0.0}
         self._engines: Dict[Tuple, Any] = {}   # hybrid engines per (top_k, rrf_k)
         self._inflight: List[_Request] = []    # the requests of the round in progress (failed as a whole if the worker dies)
+        self._outbox: Dict[Any, list] = {}     # event loop -> [(asyncio future, ok, value)] of the round in progress
 
     # ------------------------------------------------------------------ front
     def submit(self, kind: str, key: Tuple, payload: Any) -> Future:
@@ -112,9 +147,37 @@ class SearchCoalescer:
                     break
                 if r is not None:
                     _fail(r.future, err)
+            self._flush()
             with self._lock:
                 if self._thread is threading.current_thread():
                     self._thread = None
+
+    def submit_async(self, kind: str, key: Tuple, payload: Any):
+        """submit() for a caller on an event loop: returns an asyncio future of that loop (await it directly)."""
+        import asyncio
+        loop = asyncio.get_running_loop()
+        afut = loop.create_future()
+        req = _Request(kind, key, payload, _LoopFuture(loop, afut, self._outbox))
+        with self._lock:
+            if self._closed:
+                raise RuntimeError("search front is closed")
+            if self._thread is None or not self._thread.is_alive():
+                self._thread = threading.Thread(target=self._guarded, name="search-coalescer", daemon=True)
+                self._thread.start()
+        self._q.put(req)
+        return afut
+
+    def _flush(self):
+        """Hand the collected answers to their event loops: one wake-up per loop and round."""
+        if not self._outbox:
+            return
+        out = list(self._outbox.items())
+        self._outbox.clear()
+        for loop, items in out:
+            try:
+                loop.call_soon_threadsafe(_set_many, items)
+            except RuntimeError:      # the loop is closed: nobody is waiting any more
+                pass
 
     def close(self):
         with self._lock:
@@ -199,6 +262,7 @@ class SearchCoalescer:
                     for r in chunk:
                         _fail(r.future, e)
             self._inflight = []
+            self._flush()
             self.stats["busy_s"] += time.perf_counter() - t0
 
     def _run_collective(self):
@@ -260,6 +324,7 @@ class SearchCoalescer:
                             for r in d_chunk + s_chunk:
                                 _fail(r.future, e)
             self._inflight = []
+            self._flush()
             self.stats["busy_s"] += time.perf_counter() - t0
 
     def _one_by_one(self, kind: str, key: Tuple, chunk: List[_Request]):

@@ -3,6 +3,7 @@ compliance.py:28-60 record, :157-190 log_retrieval); kept because
 RetrievalResult.audit_trail carries an AuditLog."""
 from __future__ import annotations
 
+import random
 import uuid
 from dataclasses import dataclass, field
 from datetime import datetime
@@ -35,6 +36,9 @@ class AuditLog:
         return d
 
 
+_ID_RNG = random.Random(uuid.uuid4().int)   # seeded once from the OS
+
+
 class ComplianceManager:
     def __init__(self, enable_audit: bool = True, enable_versioning: bool = True):
         self.enable_audit = enable_audit
@@ -44,7 +48,10 @@ class ComplianceManager:
     def _log(self, kind: AuditEventType, data: Dict[str, Any]) -> Optional[AuditLog]:
         if not self.enable_audit:
             return None
-        entry = AuditLog(event_id=uuid.uuid4().hex, event_type=kind, timestamp=datetime.now().isoformat(),
+        # a random 128-bit id with the version / variant bits of a UUID4, from the process PRNG: uuid.uuid4() is one urandom
+        # system call per entry, and a retrieve() writes an entry per returned chunk (reference pipeline.py:279-293)
+        event_id = "%032x" % ((_ID_RNG.getrandbits(128) & ~(0xF << 76) & ~(0x3 << 62)) | (4 << 76) | (0x2 << 62))
+        entry = AuditLog(event_id=event_id, event_type=kind, timestamp=datetime.now().isoformat(),
                          user_id=None, session_id=None, event_data=data)
         self.audit_logs.append(entry)
         return entry

@@ -113,21 +113,7 @@ class EmbeddingCache:
             key, fn, key_parts = args[0], args[2], (args[0], args[1])
         else:
             raise TypeError("get_or_compute requires at least key and compute_fn")
-        cache = self
-
-        class _Compute:
-            def __await__(self_inner):
-                async def _run():
-                    got = cache._sync_get(*key_parts)
-                    if got is not None:
-                        return got
-                    takes_key = getattr(getattr(fn, "__code__", None), "co_argcount", 0) != 0
-                    value = await (fn(key) if takes_key else fn())
-                    cache._sync_put(key, value)  # stored under the plain key, as the reference does
-                    return value
-                return _run().__await__()
-
-        return _Compute()
+        return _Compute(self, key, fn, key_parts)
 
     def clear(self) -> None:
         with self._lock:
@@ -143,6 +129,27 @@ class EmbeddingCache:
     def reset_stats(self) -> None:
         with self._lock:
             self._stats = CacheStats(current_size=len(self._cache))
+
+
+class _Compute:
+    """The awaitable get_or_compute returns (one class for all calls: building a class per request showed in the profile)."""
+    __slots__ = ("cache", "key", "fn", "key_parts")
+
+    def __init__(self, cache, key, fn, key_parts):
+        self.cache, self.key, self.fn, self.key_parts = cache, key, fn, key_parts
+
+    async def _run(self):
+        got = self.cache._sync_get(*self.key_parts)
+        if got is not None:
+            return got
+        fn = self.fn
+        takes_key = getattr(getattr(fn, "__code__", None), "co_argcount", 0) != 0
+        value = await (fn(self.key) if takes_key else fn())
+        self.cache._sync_put(self.key, value)  # stored under the plain key, as the reference does
+        return value
+
+    def __await__(self):
+        return self._run().__await__()
 
 
 class DeviceEmbeddingTable:

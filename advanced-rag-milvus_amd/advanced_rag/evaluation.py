@@ -7,6 +7,8 @@ from collections import deque
 from dataclasses import asdict, dataclass
 from typing import Any, Dict, List, Optional
 
+import math
+
 import numpy as np
 
 
@@ -47,31 +49,32 @@ class RAGEvaluator:
 
     async def evaluate_retrieval(self, query: str, results: List[Dict[str, Any]],
                                  context: Optional[Dict[str, Any]] = None) -> EvaluationMetrics:
+        # plain Python arithmetic: the lists hold <= rerank_top_k entries, where a numpy call costs more than the sum it takes
         truth = set((context or {}).get("relevant_doc_ids", []) or [])
         ids = [r.get("id") for r in results]
-        hits = [i in truth for i in ids]
+        hits = [i in truth for i in ids] if truth else [False] * len(ids)
         precision = sum(hits) / len(ids) if ids and truth else 0.0
         recall = sum(hits) / len(truth) if truth else 0.0
         mrr = next((1.0 / (r + 1) for r, h in enumerate(hits) if h), 0.0)
-        dcg = sum(1.0 / np.log2(r + 2) for r, h in enumerate(hits) if h)
-        ideal = sum(1.0 / np.log2(r + 2) for r in range(min(len(truth), len(ids))))
-        scores = np.array([float(r.get("score", 0.0)) for r in results], dtype=np.float64)
+        dcg = sum(1.0 / math.log2(r + 2) for r, h in enumerate(hits) if h)
+        ideal = sum(1.0 / math.log2(r + 2) for r in range(min(len(truth), len(ids))))
+        scores = [float(r.get("score", 0.0)) for r in results]
         q_tokens = set(query.lower().split())
-        seen = set()
-        for r in results:
-            seen |= set((r.get("content") or "").lower().split())
-        coverage = len(q_tokens & seen) / len(q_tokens) if q_tokens else 0.0
         token_sets = [set((r.get("content") or "").lower().split()) for r in results]
+        seen = set().union(*token_sets) if token_sets else set()
+        coverage = len(q_tokens & seen) / len(q_tokens) if q_tokens else 0.0
         sims = [len(a & b) / (len(a | b) or 1) for i, a in enumerate(token_sets) for b in token_sets[i + 1:]]
-        diversity = 1.0 - float(np.mean(sims)) if sims else 0.0
-        confidence = float(scores.mean()) if scores.size else 0.0
-        uncertainty = float(scores.std()) if scores.size else 1.0
-        top = float(scores.max()) if scores.size else 0.0
-        risk = float(np.clip(0.25 * (1 - min(1.0, confidence)) + 0.2 * (1 - diversity) + 0.3 * (1 - min(1.0, top))
-                             + 0.25 * (1 - coverage), 0.0, 1.0)) if results else 1.0
-        if scores.size:
-            e = np.exp(scores - scores.max())
-            self.score_distributions_history.append(e / (e.sum() + 1e-12))
+        diversity = 1.0 - math.fsum(sims) / len(sims) if sims else 0.0
+        n = len(scores)
+        confidence = math.fsum(scores) / n if n else 0.0
+        uncertainty = math.sqrt(math.fsum((x - confidence) ** 2 for x in scores) / n) if n else 1.0   # population std, as ndarray.std
+        top = max(scores) if n else 0.0
+        risk = min(1.0, max(0.0, 0.25 * (1 - min(1.0, confidence)) + 0.2 * (1 - diversity) + 0.3 * (1 - min(1.0, top))
+                            + 0.25 * (1 - coverage))) if results else 1.0
+        if n:
+            e = [math.exp(x - top) for x in scores]
+            z = math.fsum(e) + 1e-12
+            self.score_distributions_history.append(np.array([x / z for x in e], dtype=np.float64))
         return EvaluationMetrics(precision, recall, mrr, float(dcg / ideal) if ideal else 0.0, risk,
                                  float(1.0 - risk), float(coverage), float(diversity), confidence, uncertainty)
 

@@ -695,9 +695,9 @@ class MilvusIndexManager:
             if front is not None:
                 params = self._search_params(coll, search_params)
                 query = self._as_sparse_payload(query_embedding) if coll.kind == "sparse" else query_embedding
-                fut = front.submit("sparse" if coll.kind == "sparse" else "dense",
-                                   (collection_name, int(top_k), filters, self._params_key(params)), query)
-                ids, sc = await asyncio.wait_for(asyncio.wrap_future(fut), timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)
+                fut = front.submit_async("sparse" if coll.kind == "sparse" else "dense",
+                                         (collection_name, int(top_k), filters, self._params_key(params)), query)
+                ids, sc = await asyncio.wait_for(fut, timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)
                 return self._format_hits(ids, sc)
             return await asyncio.wait_for(
                 asyncio.to_thread(self._search_blocking, query_embedding, collection_name, top_k, filters,
@@ -733,12 +733,12 @@ class MilvusIndexManager:
         if not len(payload[0]):
             return None
         w = list(weights) + [0.0] * (2 - len(weights))
-        fut = front.submit("hybrid", (int(top_k), filters, drop, int(rrf_k)), (dense_embedding, payload, float(w[0]), float(w[1])))
+        fut = front.submit_async("hybrid", (int(top_k), filters, drop, int(rrf_k)), (dense_embedding, payload, float(w[0]), float(w[1])))
         try:
             # no timer of its own: the caller (HybridRetriever.retrieve) already bounds the whole request with
             # RetrievalConstants.TIMEOUT_SECONDS, and a wait_for here is a task + a timer handle per request on the event
             # loop that serves every in-flight retrieve()
-            res = await asyncio.wrap_future(fut)
+            res = await fut
         except Exception:
             return None
         if res is None:
@@ -783,7 +783,7 @@ class MilvusIndexManager:
         front = self._coalescer(self.collections["semantic_index"]) if "semantic_index" in self.collections else None
         if front is None or front.collective or max(len(x) for x in lists) > 256:
             return self._fuse_output(row_to_id, *await asyncio.to_thread(self._fuse_rows_blocking, lists, key))
-        rows, scores, methods = await asyncio.wait_for(asyncio.wrap_future(front.submit("fuse", key, lists)),
+        rows, scores, methods = await asyncio.wait_for(front.submit_async("fuse", key, lists),
                                                        timeout=IndexingConstants.MILVUS_TIMEOUT_SECONDS)
         return self._fuse_output(row_to_id, rows, scores, methods)
 
@@ -791,6 +791,11 @@ class MilvusIndexManager:
     async def _run_encoder(self, fn, *args):
         if asyncio.iscoroutinefunction(fn):
             return await fn(*args)
+        if getattr(self.embedding_generator, "run_inline", False):
+            # the generator declares its synchronous hooks cheap (a lookup, a hash): no thread-pool hop per request (the
+            # reference offloads every sync hook, indexing.py:610-620 — right for a model forward, 60 us of pure overhead
+            # for a table)
+            return fn(*args)
         return await asyncio.get_event_loop().run_in_executor(self.embedding_executor, lambda: fn(*args))
 
     async def _generate_semantic_embeddings_batch(self, texts: List[str]) -> List[np.ndarray]:
@@ -858,7 +863,7 @@ class MilvusIndexManager:
             front = self._encode_front(gen)
             if front is not None:        # the misses of a round share ONE encoder forward (batching.py::_enqueue_encode)
                 self.device_cache_stats["misses"] += 1
-                return await asyncio.wrap_future(front.submit("encode", ("encode",), (key, text)))
+                return await front.submit_async("encode", ("encode",), (key, text))
             return await asyncio.get_event_loop().run_in_executor(self.embedding_executor, self._device_query_embedding, text)
         front = self._encode_front(gen)
         if front is not None:
@@ -866,7 +871,7 @@ class MilvusIndexManager:
             key = EmbeddingCache._materialize_key(text)
 
             async def compute_batched() -> np.ndarray:   # the host cache holds host arrays (reference indexing.py:601-627)
-                row = await asyncio.wrap_future(front.submit("encode", ("encode",), (key, text)))
+                row = await front.submit_async("encode", ("encode",), (key, text))
                 return await asyncio.get_event_loop().run_in_executor(self.embedding_executor, lambda: row.cpu().numpy())
             return await get_semantic_cache().get_or_compute(text, compute_batched)
 

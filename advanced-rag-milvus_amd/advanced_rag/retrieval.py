@@ -32,6 +32,7 @@ logger = logging.getLogger(__name__)
 _TROUBLE_WORDS = ("error", "exception", "stack trace", "failed", "failure", "bug")
 _SUMMARY_WORDS = ("summarize", "summary", "tl;dr", "overview")
 _METHOD_ORDER = ("semantic", "sparse", "domain")
+_METHODS_OF_MASK = tuple(tuple(m for b, m in enumerate(_METHOD_ORDER) if (mask >> b) & 1) for mask in range(8))
 
 
 class QueryClassifier:
@@ -235,12 +236,23 @@ class HybridRetriever:
         if ranked is None:
             cfg.dense_weight, cfg.sparse_weight = saved   # the general path applies the adapter itself
             return None
-        now = datetime.utcnow()
+        now = None
         fused = []
-        for hit, score, mask in ranked:
+        for hit, score, mask in ranked:     # _finish_fused_hit, inlined for the 20 hits of every request
             hit["method"] = _METHOD_ORDER[0] if mask & 1 else _METHOD_ORDER[1]
             hit["original_score"] = hit["score"]
-            fused.append(self._finish_fused_hit(hit, score, [b for b in range(3) if (mask >> b) & 1], now))
+            hit.pop("_row", None)
+            hit["score"] = score
+            hit["retrieval_methods"] = list(_METHODS_OF_MASK[mask & 7])
+            meta = hit.get("metadata")
+            if isinstance(meta, dict) and meta.get("timestamp") and "recency" not in meta:
+                now = now or datetime.utcnow()
+                try:
+                    age_days = max(0.0, (now - datetime.fromisoformat(str(meta["timestamp"]))).total_seconds() / 86400.0)
+                    meta["recency"] = float(1.0 / (1.0 + age_days))
+                except Exception:
+                    pass
+            fused.append(hit)
         return fused
 
     async def _tagged_search(self, method: str, embedding, collection: str, top_k: int, filters, params):
@@ -368,7 +380,8 @@ class HybridRetriever:
             new_scores = await self.reranker.score([(query, r["content"]) for r in results])
         else:
             # the reference's placeholder: retrieval score + N(0, 0.01) (retrieval.py:549-553)
-            new_scores = [r["score"] + np.random.normal(0, 0.01) for r in results]
+            # (one vector draw: the same values, in the same order, as a scalar draw per result from numpy's global stream)
+            new_scores = [r["score"] + e for r, e in zip(results, np.random.normal(0, 0.01, len(results)).tolist())]
         for r, s in zip(results, new_scores):
             r["rerank_score"] = s
             r["original_retrieval_score"] = r["score"]

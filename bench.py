@@ -859,6 +859,8 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
     flatS = [s for batch in SQ for s in batch]
 
     class Gen:
+        run_inline = True   # table lookups: the manager calls them on the event loop instead of hopping to its thread pool
+
         def encode_semantic(self, text):
             return flatQ[int(text[1:])]
 
@@ -984,10 +986,94 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
             m2.embedding_executor.shutdown(wait=False)
         api["note"] = ("AdvancedRAGPipeline.retrieve() coroutines on one event loop, host buffers in, Python result objects out; "
                        "engine `value` above is the same kernels fed with device-resident pre-batched queries")
+    # ---- the same entry points with the QUERY ENCODER in the path (reference: 10 - 20 ms of a request's budget,
+    # ARCHITECTURE.md:321-328; indexing.py:601-627 embeds each request alone): a random-init sentence encoder of the shard's
+    # width (bge-base shape at 768), ~32-token query texts that are all cache misses; the batching front encodes the misses
+    # of a round in ONE forward and hands the rows to the search without a host hop
+    with_encoder = None
+    if world == 1 and not args.no_api_concurrent:
+        import torch
+        from advanced_rag.encoders import EncoderConfig, SentenceEncoder
+        ecfg = (EncoderConfig(hidden=args.dim, layers=12, heads=args.dim // 64, intermediate=4 * args.dim) if args.dim >= 768
+                else EncoderConfig(hidden=args.dim))
+        enc = SentenceEncoder(ecfg, device="cuda:0", max_len=64, batch_size=256)
+        words = ("retrieval augmented generation pipeline vector index sparse dense hybrid fusion rerank latency throughput shard "
+                 "memory bandwidth kernel query document chunk embedding filter metadata timestamp entropy redundancy").split()
+
+        def qtext(i):   # ~30 tokens, distinct per i, ends in the number that keys the sparse table
+            r = np.random.default_rng(i)
+            return " ".join(r.choice(words, 24)) + f" about item number q{i}"
+
+        class EncGen:
+            run_inline = True           # the sparse side is a table lookup; the dense side goes through the batching front
+            encode_to_device = enc.encode_to_device
+            encode_semantic = enc.encode_semantic
+            encode_semantic_batch = enc.encode_semantic_batch
+
+            def encode_sparse(self, text):
+                qi, qv = flatS[int(text.rsplit("q", 1)[1]) % len(flatS)]
+                return {"indices": qi.tolist(), "values": qv.tolist()}
+
+            def encode_domain(self, text, domain=None):
+                return np.zeros(768, np.float32)
+
+        m3 = MilvusIndexManager(semantic_dim=args.dim, sparse_dim=SPARSE_DIM, connect=False, device_embedding_cache=1 << 16)
+        m3.attach_shards([h], synthetic_rows=h.num_rows)
+        m3.embedding_generator = EncGen()
+        pipe3 = AdvancedRAGPipeline(connect_to_milvus=False, config=PipelineConfig(top_k=args.top_k))
+        pipe3.index_manager = m3
+        pipe3.retriever.index_manager = m3
+        retr3 = HybridRetriever(m3, RetrievalConfig(top_k=args.top_k))
+        counter = [0]
+
+        async def seq_enc(k):
+            lat_e = []
+            for _ in range(k + 5):
+                counter[0] += 1
+                t0 = time.perf_counter()
+                out = await retr3.retrieve(qtext(counter[0]), profile_hint="default")
+                dt = (time.perf_counter() - t0) * 1e3
+                assert len(out) == args.top_k
+                lat_e.append(dt)
+            return lat_e[5:]
+
+        async def burst_enc(n_total, in_flight):
+            sem = asyncio.Semaphore(in_flight)
+            lat3 = []
+
+            async def one():
+                async with sem:
+                    counter[0] += 1
+                    text = qtext(counter[0])
+                    t0 = time.perf_counter()
+                    res, _m = await pipe3.retrieve(text, context={"retrieval_profile": "default"})
+                    lat3.append((time.perf_counter() - t0) * 1e3)
+                    assert 0 < len(res) <= pipe3.config.rerank_top_k
+            t0, c0 = time.perf_counter(), time.process_time()
+            await asyncio.gather(*[one() for _ in range(n_total)])
+            return lat3, time.perf_counter() - t0, time.process_time() - c0
+
+        with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+            lat_e = asyncio.run(seq_enc(min(n, 100)))
+            asyncio.run(burst_enc(64, 64))
+            f0, st0 = enc.forwards, dict(m3._front.stats)
+            lat3, wall, cpu = asyncio.run(burst_enc(16 * 64, 64))
+        st1 = m3._front.stats
+        with_encoder = {
+            "encoder": f"random-init BERT hidden {ecfg.hidden} x {ecfg.layers} layers (fp16), ~30-token queries, every request a cache miss",
+            "p50_retrieve_ms_with_encoder": float(np.percentile(lat_e, 50)), "p95_retrieve_ms_with_encoder": float(np.percentile(lat_e, 95)),
+            "in_flight_64": {"requests": 16 * 64, "qps": 16 * 64 / wall, "p50_ms": float(np.percentile(lat3, 50)),
+                             "p95_ms": float(np.percentile(lat3, 95)), "process_cpu_us_per_request": cpu / (16 * 64) * 1e6,
+                             "encoder_forwards": enc.forwards - f0,
+                             "texts_per_encoder_forward": (st1["encoded_texts"] - st0["encoded_texts"]) / max(1, enc.forwards - f0),
+                             "rounds": st1["rounds"] - st0["rounds"]}}
+        m3._front.close()
+        m3.embedding_executor.shutdown(wait=False)
     if world > 1:
         mgr.stop_workers()
     mgr.embedding_executor.shutdown(wait=False)
-    return {"retrieve_shards": world,
+    return {"retrieve_shards": world, **({"with_query_encoder": with_encoder,
+                                          "p50_retrieve_ms_with_encoder": with_encoder["p50_retrieve_ms_with_encoder"]} if with_encoder else {}),
             "p50_retrieve_ms": float(np.percentile(lat, 50)), "p95_retrieve_ms": float(np.percentile(lat, 95)),
             "p50_pipeline_retrieve_ms": float(np.percentile(lat2, 50)),
             "p95_pipeline_retrieve_ms": float(np.percentile(lat2, 95)), "latency_queries": n,

@@ -62,12 +62,15 @@ class FakeFront(SearchCoalescer):
                 else:
                     k = r.key[1]
                     r.future.set_result((rng.integers(0, N_ROWS, k), np.sort(rng.random(k).astype(np.float32))[::-1].copy()))
+            self._flush()
 
 
 flatQ = np.random.default_rng(1).standard_normal((1024, DIM)).astype(np.float32)
 
 
 class Gen:
+    run_inline = os.environ.get("PROBE_INLINE_GEN", "1") == "1"   # a table lookup: no thread-pool hop (indexing._run_encoder)
+
     def encode_semantic(self, text):
         return flatQ[int(text[1:]) % 1024]
 
