@@ -21,6 +21,7 @@ HR_N_PHASES = 10
 PHASE_NAMES = ("prep", "dense_scan", "group_select", "refine", "topk",
                "sparse_scan", "sparse_select", "sparse_refine", "sparse_topk", "finish_fused")
 HR_DEBUG_FINISH_MODE, HR_DEBUG_FAIL_NEXT_BUILD, HR_DEBUG_DENSE_KERNELS, HR_DEBUG_SPARSE_RPB, HR_DEBUG_GROUP_ROWS = 1, 2, 3, 4, 5
+HR_DEBUG_NO_TRIM = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhbmrag.so")

@@ -121,6 +121,9 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
     FINISH_STAMP(1);
     select_groups_block(a.sel, q, s_bmax, s_cand, sh, sel_bucket);
     __syncthreads();
+    // the candidates that survived the trim sit at the front (GroupSelArgs::K_trim): only their rows are refined
+    const int n_live_slots = min(sh.n_live, a.sel.C) * a.group_rows;
+    for (int slot = n_live_slots + tid; slot < n_slots; slot += kFinishThreads) s_key[slot] = 0ull;
     FINISH_STAMP(2);
 
     if (a.kind == 0) {
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
         for (int k = tid; k < a.dim; k += kFinishThreads) qq[k] = a.q[(int64_t)q * a.dim + k];
         __syncthreads();
         const double qn2 = a.qn2[q];
-        for (int slot = tid; slot < n_slots; slot += kFinishThreads) {
+        for (int slot = tid; slot < n_live_slots; slot += kFinishThreads) {
             float sc = 0.f;
             int32_t row = -1;
             const bool ok = a.dtype == HR_F16
@@ -145,11 +148,11 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
         int32_t* s_idx = reinterpret_cast<int32_t*>(s_filter + kFilterBits / 32);
         float* s_val = reinterpret_cast<float*>(s_idx + a.q_cap);
         const int nt = refine_sparse_stage_query(a.q_indptr, a.q_idx, a.q_val, q, a.q_cap, s_filter, s_idx, s_val);
-        const int n_chains = (n_slots + 63) / 64;
+        const int n_chains = (n_live_slots + 63) / 64;
         const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
         for (int chain = wid; chain < n_chains; chain += kFinishThreads / 64) {
             const int slot0 = chain * 64;
-            const int n_here = min(64, n_slots - slot0);
+            const int n_here = min(64, n_live_slots - slot0);
             refine_sparse_chain(a.indptr, a.idx, a.val, a.rowmask, s_cand, a.group_rows, a.n_rows, slot0, n_here,
                                 s_filter, s_idx, s_val, nt, [&](int slot, bool keep, float score, int64_t doc) {
                                     s_key[slot] = keep ? rank_key(score, (uint32_t)doc) : 0ull;

@@ -410,6 +410,7 @@ hipError_t launch_scan_bigq_g(const hr_index* h, hipStream_t s, const chunk_t* q
 // contraction to the register-resident pass where both apply
 int g_dense_kernels = 0;
 int g_sparse_rpb = 0;     // HR_DEBUG_SPARSE_RPB: doc ranges per sparse-scan block (0 = by shard size)
+int g_no_trim = 0;        // HR_DEBUG_NO_TRIM: 1 = refine all C candidate groups (A/B of the data-dependent candidate set)
 int g_group_rows = 0;     // HR_DEBUG_GROUP_ROWS: candidate-group size of handles created from now on (0 = by shard size)
 bool qreg_supported(const hr_index* h) {
     return !(g_dense_kernels & 1) && h->dtype == HR_F16 && h->KT == 24;
@@ -454,7 +455,7 @@ int max_groups_for_dim(const hr_index* h) {
 
 // Two-level candidate selection: per-bucket maxima, then one block per query — for one modality or for both
 // modalities of a hybrid search in one pair of launches (select.h: GroupSelPair).
-int group_sel_args(hr_index* h, Workspace* ws, int B, int64_t n_groups, int C, GroupSelArgs* a) {
+int group_sel_args(hr_index* h, Workspace* ws, int B, int64_t n_groups, int C, GroupSelArgs* a, const TopkArgs* t = nullptr) {
     const int64_t n_buckets = (n_groups + kBucketGroups - 1) / kBucketGroups;
     HIP_TRY(h, ws->bmax.ensure((size_t)B * n_buckets * sizeof(float)));
     a->gmax = ws->gmax.as<float>();
@@ -465,6 +466,11 @@ int group_sel_args(hr_index* h, Workspace* ws, int B, int64_t n_groups, int C, G
     a->two_level = n_groups > C && n_buckets > C;
     a->cand = ws->cand.as<int32_t>();
     a->a_cut = ws->acut.as<float>();
+    // the data-dependent candidate set: trim against the K-th largest group maximum with the error bound of the list's proof
+    a->K_trim = (t && !g_no_trim) ? t->K : 0;
+    a->eps_abs = t ? t->eps_abs : 0.f;
+    a->eps_rel = t ? t->eps_rel : 0.f;
+    a->eps_abs_q = t ? t->eps_abs_q : nullptr;
     return HR_OK;
 }
 int launch_group_select_pair(hr_index* h, hipStream_t s, int B, const GroupSelPair& p) {
@@ -479,10 +485,10 @@ int launch_group_select_pair(hr_index* h, hipStream_t s, int B, const GroupSelPa
     HIP_TRY(h, hipGetLastError());
     return HR_OK;
 }
-int launch_group_select(hr_index* h, Workspace* ws, hipStream_t s, int B, int64_t n_groups, int C) {
+int launch_group_select(hr_index* h, Workspace* ws, hipStream_t s, int B, int64_t n_groups, int C, const TopkArgs* t = nullptr) {
     GroupSelPair p{};
     p.n = 1;
-    HR_TRY(group_sel_args(h, ws, B, n_groups, C, &p.m[0]));
+    HR_TRY(group_sel_args(h, ws, B, n_groups, C, &p.m[0], t));
     return launch_group_select_pair(h, s, B, p);
 }
 int launch_topk_pair(hr_index* h, hipStream_t s, int B, const TopkPair& p) {
@@ -636,6 +642,10 @@ FinishMod finish_mod_dense(hr_index* h, Workspace* ws, const float* d_q, int B, 
     m.sel.two_level = n_groups > C && m.sel.n_buckets > C;
     m.sel.a_cut = ws->acut.as<float>();
     m.topk = dense_topk_args(h, ws, C, GR, k, d_ids, d_scores, d_flags);
+    m.sel.K_trim = g_no_trim ? 0 : k;
+    m.sel.eps_abs = m.topk.eps_abs;
+    m.sel.eps_rel = m.topk.eps_rel;
+    m.sel.eps_abs_q = m.topk.eps_abs_q;
     m.rowmask = d_mask;
     m.tiles = h->tiles.as<chunk_t>();
     m.KT = h->KT;
@@ -661,6 +671,10 @@ FinishMod finish_mod_sparse(hr_index* h, Workspace* ws, const int64_t* d_qptr, c
     m.sel.two_level = n_groups > C && m.sel.n_buckets > C;
     m.sel.a_cut = ws->acut.as<float>();
     m.topk = sparse_topk_args(h, ws, C, GR, k, d_ids, d_scores, d_flags);
+    m.sel.K_trim = g_no_trim ? 0 : k;
+    m.sel.eps_abs = m.topk.eps_abs;
+    m.sel.eps_rel = m.topk.eps_rel;
+    m.sel.eps_abs_q = m.topk.eps_abs_q;
     m.rowmask = d_mask;
     m.indptr = h->s_indptr.as<int64_t>();
     m.idx = h->s_idx.as<int32_t>();
@@ -744,7 +758,8 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
     }
     {
         Span sp(h, s, PH_GSEL);
-        HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
+        const TopkArgs t = dense_topk_args(h, ws, C, GR, k, d_ids, d_scores, d_flags);
+        HR_TRY(launch_group_select(h, ws, s, B, n_groups, C, &t));
     }
     {
         Span sp(h, s, PH_REFINE);
@@ -821,7 +836,8 @@ int sparse_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const int64
     }
     {
         Span sp(h, s, PH_SGSEL);
-        HR_TRY(launch_group_select(h, ws, s, B, n_groups, C));
+        const TopkArgs t = sparse_topk_args(h, ws, C, GR, k, d_ids, d_scores, d_flags);
+        HR_TRY(launch_group_select(h, ws, s, B, n_groups, C, &t));
     }
     {
         Span sp(h, s, PH_SREFINE);
@@ -868,8 +884,10 @@ int hybrid_finish_enqueue(hr_index* h, Workspace* wd, Workspace* wsp, hipStream_
         Span sp(h, s, PH_GSEL);
         GroupSelPair p{};
         p.n = 2;
-        HR_TRY(group_sel_args(h, wd, B, ng_d, C, &p.m[0]));
-        HR_TRY(group_sel_args(h, wsp, B, ng_s, C, &p.m[1]));
+        const TopkArgs td = dense_topk_args(h, wd, C, GRd, k, d_ids, d_scores, d_flags);
+        const TopkArgs ts = sparse_topk_args(h, wsp, C, GRs, k, s_ids, s_scores, s_flags);
+        HR_TRY(group_sel_args(h, wd, B, ng_d, C, &p.m[0], &td));
+        HR_TRY(group_sel_args(h, wsp, B, ng_s, C, &p.m[1], &ts));
         HR_TRY(launch_group_select_pair(h, s, B, p));
     }
     {
@@ -1811,6 +1829,9 @@ int hr_debug_option(hr_index* h, int key, int value) {
         case HR_DEBUG_GROUP_ROWS:
             if (value != 0 && value != 16 && value != 64) return fail(h, HR_EINVAL, "group rows must be 0, 16 or 64");
             g_group_rows = value;
+            return HR_OK;
+        case HR_DEBUG_NO_TRIM:
+            g_no_trim = value != 0;
             return HR_OK;
         case HR_DEBUG_FAIL_NEXT_BUILD:
             if (!h) return fail(nullptr, HR_EINVAL, "null handle");

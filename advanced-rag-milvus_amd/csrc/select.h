@@ -17,6 +17,8 @@ struct SelectScratch {
     int digit;
     int remaining;
     int count;
+    int n_live;      // select_groups_block: candidate slots that hold a group after the trim (the rest are -1)
+    unsigned gk_bits; // ... and the K-th largest candidate maximum it trimmed against
 };
 
 // One 8-bit radix pass: histogram of digit `shift` over the keys that match
@@ -116,6 +118,14 @@ struct GroupSelArgs {
     int two_level;        // n_groups > C && n_buckets > C
     int32_t* cand;        // [B][C] out
     float* a_cut;         // [B] out
+    // Data-dependent candidate set (round 4): with K_trim = the length of the list being built, a group whose maximum lies
+    // more than twice the scan's error bound below the K_trim-th largest group maximum cannot hold a row of the top K_trim
+    // (K_trim groups each hold a row at or above that maximum, up to the error; every row of the other group lies below it,
+    // up to the error) — such candidates are dropped (slot = -1), the kept ones moved to the front in descending order of
+    // their maxima, and a_cut becomes the largest dropped maximum.  eps_* as in TopkArgs.  0 = keep all C.
+    int K_trim;
+    float eps_abs, eps_rel;
+    const float* eps_abs_q;
 };
 struct GroupSelPair {
     GroupSelArgs m[2];
@@ -161,7 +171,10 @@ __device__ inline void select_groups_block(const GroupSelArgs& a, int q, const f
     const float NEG_INF = -__builtin_inff();
     if (n_groups <= C) {
         for (int i = threadIdx.x; i < C; i += blockDim.x) out[i] = (i < n_groups) ? i : -1;
-        if (threadIdx.x == 0) a_cut[q] = NEG_INF;
+        if (threadIdx.x == 0) {
+            a_cut[q] = NEG_INF;
+            sh.n_live = C;
+        }
         return;
     }
     // ---- level 2: the C buckets with the largest maxima
@@ -201,6 +214,46 @@ __device__ inline void select_groups_block(const GroupSelArgs& a, int q, const f
             if (slot < C) out[slot] = (int32_t)key_row(kk);
         }
     }
+    if (threadIdx.x == 0) sh.n_live = C;
+    // ---- trim: keep the candidates that can still hold a row of the top K_trim (see GroupSelArgs)
+    const int K = a.K_trim;
+    if (K <= 0 || K >= C || C > (int)blockDim.x) return;      // one candidate per thread below
+    __syncthreads();
+    float* vals = reinterpret_cast<float*>(sel_bucket);         // the selected buckets are no longer needed (C <= 512 entries)
+    const int i = threadIdx.x;
+    int32_t grp = -1;
+    float v = NEG_INF;
+    if (i < C) {
+        grp = out[i];
+        v = grp >= 0 ? gm[grp] : NEG_INF;
+        vals[i] = v;
+    }
+    __syncthreads();
+    int rank = 0;                                               // position by (maximum desc, slot asc): a permutation of 0 .. C-1
+    if (i < C) {
+        for (int j = 0; j < C; ++j) {
+            const float w = vals[j];
+            rank += (w > v) || (w == v && j < i);
+        }
+        if (rank == K - 1) sh.gk_bits = __builtin_bit_cast(unsigned, v);
+    }
+    __syncthreads();
+    const float gk = __builtin_bit_cast(float, sh.gk_bits);
+    const float eps = a.eps_abs + (a.eps_abs_q ? a.eps_abs_q[q] : 0.f) + a.eps_rel * fabsf(gk);
+    const float thr = gk - 2.0f * eps - 1e-6f * fabsf(gk);      // (gk = -inf: fewer than K live groups — nothing is dropped)
+    const bool keep = i < C && grp >= 0 && (v >= thr || !(gk > NEG_INF));
+    if (threadIdx.x == 0) {
+        sh.n_live = 0;
+        sh.hist[1] = 0;   // ord_f32 of the largest dropped maximum (0 = nothing dropped)
+    }
+    __syncthreads();
+    if (i < C) {
+        if (keep) atomicMax(&sh.n_live, rank + 1);              // the kept ones are exactly the best n_live by rank
+        else if (grp >= 0) atomicMax(&sh.hist[1], ord_f32(v));
+        out[rank] = keep ? grp : -1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && sh.hist[1] != 0) a_cut[q] = fmaxf(a_cut[q], unord_f32(sh.hist[1]));
 }
 
 __global__ __launch_bounds__(1024) void select_groups_kernel(GroupSelPair p) {

@@ -234,6 +234,8 @@ def main():
                          "(CU-masked HIP streams); 0 = no masks, stream priorities only")
     ap.add_argument("--prep-stream", action="store_true", help="query prep on a third stream instead of the scan stream")
     ap.add_argument("--group-rows", type=int, choices=(0, 16, 64), default=0, help="rows per candidate group (0 = by shard size)")
+    ap.add_argument("--no-trim", action="store_true",
+                    help="refine all candidate groups (round 3's constant 64 per query) instead of the data-dependent set: A/B")
     ap.add_argument("--dense-kernel-mask", type=int, default=0,
                     help="hr_debug_option(HR_DEBUG_DENSE_KERNELS) bit mask for A/B runs")
     ap.add_argument("--finish-mode", choices=("auto", "chain", "fused"), default="auto",
@@ -283,6 +285,7 @@ def main():
     N, D, B, blk = args.rows, args.dim, args.batch, min(args.block_rows, args.rows)
     lo, hi = shard_range(N, rank, world, align=blk)
     n_local = hi - lo
+    nat.debug_option(nat.HR_DEBUG_NO_TRIM, 1 if args.no_trim else 0)
     nat.debug_option(nat.HR_DEBUG_DENSE_KERNELS, args.dense_kernel_mask)
     nat.debug_option(nat.HR_DEBUG_GROUP_ROWS, args.group_rows)
     h = nat.ShardHandle(D, nat.HR_F16, nat.HR_METRIC_COSINE, SPARSE_DIM if use_sparse else 0, local_rank)

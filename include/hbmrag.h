@@ -406,9 +406,11 @@ HR_API int hr_set_scan_cus(hr_index* h, int n_cus);
  * HR_DEBUG_SPARSE_RPB (process-wide): doc ranges one sparse-scan block walks (0 = by shard size).
  * HR_DEBUG_GROUP_ROWS (process-wide): rows per candidate group (16 or 64; 0 = by shard size) of handles created
  *   afterwards.
+ * HR_DEBUG_NO_TRIM (process-wide): 1 = refine every one of the C candidate groups of a query (round 3's behaviour) instead
+ *   of only those whose maximum is within twice the scan's error bound of the k-th largest group maximum (A/B, tests).
  * The library reads no environment variables. */
 enum { HR_DEBUG_FINISH_MODE = 1, HR_DEBUG_FAIL_NEXT_BUILD = 2, HR_DEBUG_DENSE_KERNELS = 3, HR_DEBUG_SPARSE_RPB = 4,
-       HR_DEBUG_GROUP_ROWS = 5 };
+       HR_DEBUG_GROUP_ROWS = 5, HR_DEBUG_NO_TRIM = 6 };
 HR_API int hr_debug_option(hr_index* h, int key, int value);
 
 /* ---- measurement hooks -------------------------------------------------------
