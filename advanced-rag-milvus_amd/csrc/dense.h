@@ -607,6 +607,200 @@ __global__ __launch_bounds__(64 * NW) void dense_scan_qreg_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// 256-query scan, second form (round 4): dense_scan_qreg_kernel with HALF the LDS reads — 4 waves x 64 queries, ONE wave
+// per SIMD, the 4 x KT query fragments of a wave spread over the unified 512-entry register file (groups 0, 1 in the
+// accumulator half, groups 2, 3 in the vector half: v_mfma takes A / B / C from either), the corpus streamed HBM -> LDS by
+// LDS-DMA exactly as there (stages of one row block, ring of kQregStages, one barrier per stage).  Every 1 KiB tile is read
+// from LDS by 4 waves instead of 8 and feeds 4 MFMAs per read instead of 2.  (A first form of this kernel streamed the
+// corpus into registers and let the four waves share it through the caches: the unique bytes in flight per compute unit
+// are then one wave's ring — 4 KiB — and the pass ran at 2.4 TB/s.)
+//
+// hipcc, left to itself, copies the AGPR-resident query fragments to VGPRs before every MFMA (and, with 384 query
+// registers, sees no room for a pipeline), so the k loop is written out: LDS reads, counted waits and MFMAs as inline asm.
+// What the asm owes the hardware: an accumulator is touched every 4th MFMA (no back-to-back dependence), its first MFMA of
+// a row block takes the constant 0 as C, and the epilogue's reads sit behind s_nop (the compiler's hazard recogniser
+// does not look into asm).
+template <bool FIRST>
+__device__ inline void q64_mfma_a(f32x4_t& acc, const chunk_t& tile, const chunk_t& q) {   // query fragment in an AGPR
+    if (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(tile), "a"(q));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(tile), "a"(q));
+}
+template <bool FIRST>
+__device__ inline void q64_mfma_v(f32x4_t& acc, const chunk_t& tile, const chunk_t& q) {   // query fragment in a VGPR
+    if (FIRST) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(acc) : "v"(tile), "v"(q));
+    else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(tile), "v"(q));
+}
+
+template <int KT, int NRB>
+__global__ __launch_bounds__(256, 1) void dense_scan_q64_kernel(
+    const chunk_t* __restrict__ tiles, const chunk_t* __restrict__ qfrag, const float* __restrict__ scale,
+    const uint8_t* __restrict__ rowmask, float* __restrict__ gmax, int nq, int64_t n_rows, int64_t n_super) {
+    constexpr int GW = 4, NW = 4, T = KT, NS = kQregStages;
+    constexpr int L = T / NW;                     // tiles a wave loads per stage
+    constexpr int TPS = kRowBlocksPerSuper * KT;  // tiles of one 64-row super-group, contiguous in the shard
+    constexpr int H = 4;                          // tiles whose LDS reads are issued / awaited together
+    static_assert(T % NW == 0 && T % H == 0 && (T / H) == L, "one refill tile per group of four");
+    static_assert(NRB == 1 || NRB == kRowBlocksPerSuper, "group = one row block or one super-group");
+    extern __shared__ chunk_t q64_lds[];          // ring [NS * T tiles], then the row scales of the current / next super-group
+    chunk_t* ring = q64_lds;
+    float* sc_lds = reinterpret_cast<float*>(q64_lds + NS * T * kTileChunks);
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int quad = lane >> 4;
+    const float NEG_INF = -__builtin_inff();
+    const unsigned ring_lds = (unsigned)(uintptr_t)(hr_lptr_t)ring;
+    const unsigned sc_lds_addr = (unsigned)(uintptr_t)(hr_lptr_t)sc_lds;
+    const int64_t first = blockIdx.x, step = gridDim.x;
+    if (first >= n_super) return;  // whole block
+    const int64_t n_my = (n_super - first + step - 1) / step;
+    const int64_t gmax_stride = n_super * (kRowBlocksPerSuper / NRB);
+
+    chunk_t qa[2][KT], qv[2][KT];   // this wave's 64 queries, every k-step: groups 0, 1 (AGPRs) and 2, 3 (VGPRs)
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            qa[gq][kt] = qfrag[((int64_t)(wid * GW + gq) * KT + kt) * kTileChunks + lane];
+            qv[gq][kt] = qfrag[((int64_t)(wid * GW + 2 + gq) * KT + kt) * kTileChunks + lane];
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) asm volatile("" : "+a"(qa[gq][kt]), "+v"(qv[gq][kt]));   // settled, and where they belong
+
+    // loader (as dense_scan_qreg_kernel): wave w brings tiles w, w + NW, ... of every stage
+    int64_t ld_sg = first;
+    int ld_within = wid;
+    auto issue_one = [&](int stage_slot, int l) {
+        const int64_t sg = ld_sg < n_super ? ld_sg : first;  // past the end: harmless re-read, keeps the count of loads in flight fixed
+        const chunk_t* src = tiles + (sg * TPS + ld_within + l * NW) * kTileChunks + lane;
+        __builtin_amdgcn_global_load_lds((hr_gptr_t)src, (hr_lptr_t)(ring + (stage_slot * T + wid + l * NW) * kTileChunks), 16,
+                                         0, 2 /* nt: each byte is read once */);
+    };
+    auto advance_loader = [&]() {
+        ld_within += T;
+        if (ld_within >= TPS) {
+            ld_within -= TPS;
+            ld_sg += step;
+        }
+    };
+    auto issue_scale = [&](int64_t sg, int slot) {  // wave 0 only: one more (older) operation on its counter
+        const int64_t sgc = sg < n_super ? sg : first;
+        __builtin_amdgcn_global_load_lds((hr_gptr_t)(scale + sgc * kSuperRows + lane), (hr_lptr_t)(sc_lds + slot * kSuperRows), 4, 0, 0);
+    };
+    if (wid == 0) issue_scale(first, 0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+#pragma unroll
+        for (int l = 0; l < L; ++l) issue_one(s, l);
+        advance_loader();
+    }
+
+    int st = 0;  // stage slot of the stage about to be consumed
+    int64_t sg = first;
+    for (int64_t g = 0; g < n_my; ++g, sg += step) {
+        float m[GW];
+#pragma unroll
+        for (int gq = 0; gq < GW; ++gq) m[gq] = NEG_INF;
+        if (wid == 0) issue_scale(sg + step, (int)((g + 1) & 1));  // lands >= NS - 1 stages before its first use
+        const bool tail = (sg + 1) * kSuperRows > n_rows || rowmask != nullptr;
+#pragma unroll 1
+        for (int rbi = 0; rbi < kRowBlocksPerSuper; ++rbi) {
+            f32x4_t acc[GW];
+            // own tiles of this stage have landed: at least (NS - 2) * L newer loads were issued after them
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * L) : "memory");
+            lds_barrier();
+            const int refill = st == 0 ? NS - 1 : st - 1;  // the slots of the stage everybody has just left
+            const unsigned addr = ring_lds + (unsigned)(st * T * kTileChunks + lane) * 16u;
+            chunk_t a[2][H];
+            auto read4 = [&](chunk_t (&d)[H], int half) {
+                asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"
+                             : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                             : "v"(addr), "n"((half * H) * 1024), "n"((half * H + 1) * 1024), "n"((half * H + 2) * 1024), "n"((half * H + 3) * 1024)
+                             : "memory");
+            };
+            read4(a[0], 0);
+#pragma unroll
+            for (int half = 0; half < T / H; ++half) {
+                chunk_t (&cur)[H] = a[half & 1];
+                if (half + 1 < T / H) {
+                    read4(a[(half + 1) & 1], half + 1);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3])::"memory");
+                }
+#pragma unroll
+                for (int j = 0; j < H; ++j) {
+                    const int kt = half * H + j;
+                    if (kt == 0) {
+                        q64_mfma_a<true>(acc[0], cur[j], qa[0][kt]);
+                        q64_mfma_a<true>(acc[1], cur[j], qa[1][kt]);
+                        q64_mfma_v<true>(acc[2], cur[j], qv[0][kt]);
+                        q64_mfma_v<true>(acc[3], cur[j], qv[1][kt]);
+                    } else {
+                        q64_mfma_a<false>(acc[0], cur[j], qa[0][kt]);
+                        q64_mfma_a<false>(acc[1], cur[j], qa[1][kt]);
+                        q64_mfma_v<false>(acc[2], cur[j], qv[0][kt]);
+                        q64_mfma_v<false>(acc[3], cur[j], qv[1][kt]);
+                    }
+                }
+                issue_one(refill, half);   // one refill tile per group of four: the stage's L loads spread over the stage
+            }
+            advance_loader();
+            st = (st + 1 == NS) ? 0 : st + 1;
+            // the accumulators are complete 16 cycles after the last MFMA issued; the compiler does not know they came from MFMAs
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+a"(acc[0]), "+a"(acc[1]), "+a"(acc[2]), "+a"(acc[3]));
+            // epilogue of the row block: lane holds rows quad*4..+3 of the block for query (lane & 15) of each group
+            float ok[4] = {1.f, 1.f, 1.f, 1.f};
+            const int64_t row0 = (sg * kRowBlocksPerSuper + rbi) * kRowsPerBlock + quad * 4;
+            f32x4_t sc;
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(sc)
+                         : "v"(sc_lds_addr + (unsigned)(((g & 1) * kSuperRows + rbi * kRowsPerBlock + quad * 4) * 4))
+                         : "memory");
+            if (tail) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t row = row0 + r;
+                    bool v = row < n_rows;
+                    if (v && rowmask) v = (rowmask[row >> 3] >> (row & 7)) & 1;
+                    ok[r] = v ? 1.f : 0.f;
+                }
+            }
+#pragma unroll
+            for (int gq = 0; gq < GW; ++gq) {
+                const int q = 16 * (wid * GW + gq) + (lane & 15);
+                float mr = NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[gq][r] * sc[r];
+                    v = (ok[r] != 0.f) ? v : NEG_INF;
+                    mr = fmaxf(mr, v);
+                }
+                if (NRB == 1) {
+                    mr = col4_max(mr);
+                    if (lane < 16 && q < nq) gmax[(int64_t)q * gmax_stride + sg * kRowBlocksPerSuper + rbi] = mr;
+                } else {
+                    m[gq] = fmaxf(m[gq], mr);
+                }
+            }
+        }
+        if (NRB != 1) {
+#pragma unroll
+            for (int gq = 0; gq < GW; ++gq) {
+                const int q = 16 * (wid * GW + gq) + (lane & 15);
+                float v = m[gq];
+                v = col4_max(v);
+                if (lane < 16 && q < nq) gmax[(int64_t)q * gmax_stride + sg] = v;
+            }
+        }
+    }
+    // LDS DMA still in flight must land before the block's LDS is handed to another block
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------
 // 256-query scan as a tiled contraction (any KT >= 8, fp16 shards): BASELINE config 5's shape (D = 1024, B = 256).
 // (GQ = 8 is the same kernel for 65..128 queries: 64 accumulator registers per wave, half the query ring.)
 //

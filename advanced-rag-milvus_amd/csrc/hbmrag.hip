@@ -429,6 +429,29 @@ hipError_t launch_scan_qreg_g(const hr_index* h, hipStream_t s, const chunk_t* q
     return group_rows_for(h, h->n_rows) == 16 ? launch_scan_qreg<24, 1, 2, 8>(h, s, qfrag, mask, gmax, nq, n_super)
                                               : launch_scan_qreg<24, 4, 2, 8>(h, s, qfrag, mask, gmax, nq, n_super);
 }
+// 256 queries per pass, second form: 4 waves x 64 queries in registers (one wave per SIMD, the whole 512-entry register
+// file), the corpus through the same LDS-DMA ring with half the LDS reads (dense_scan_q64_kernel).
+// HR_DEBUG_DENSE_KERNELS bit 16 selects it.
+hipError_t launch_scan_q64_g(const hr_index* h, hipStream_t s, const chunk_t* qfrag, const uint8_t* mask, float* gmax,
+                             int nq, int64_t n_super) {
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(n_super, (int64_t)scan_cus(h)));
+    const size_t lds = (size_t)kQregStages * 24 * 1024 + 2 * kSuperRows * sizeof(float);
+    static bool ready = false;
+    if (!ready) {
+        hipError_t e = hipFuncSetAttribute((const void*)dense_scan_q64_kernel<24, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)dense_scan_q64_kernel<24, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        ready = true;
+    }
+    if (group_rows_for(h, h->n_rows) == 16)
+        hipLaunchKernelGGL((dense_scan_q64_kernel<24, 1>), dim3((unsigned)blocks), dim3(256), lds, s, h->tiles.as<chunk_t>(), qfrag,
+                           h->scale.as<float>(), mask, gmax, nq, h->n_rows, n_super);
+    else
+        hipLaunchKernelGGL((dense_scan_q64_kernel<24, 4>), dim3((unsigned)blocks), dim3(256), lds, s, h->tiles.as<chunk_t>(), qfrag,
+                           h->scale.as<float>(), mask, gmax, nq, h->n_rows, n_super);
+    return hipGetLastError();
+}
 // 256-query pass as a tiled contraction (dense_scan_gemm_kernel): fp16 shards of any row length from 8 tiles up;
 // serves the shapes the register-resident form cannot (D = 1024: BASELINE config 5).
 bool gemm_supported(const hr_index* h) {
@@ -736,8 +759,9 @@ int dense_search_enqueue(hr_index* h, Workspace* ws, hipStream_t s, const float*
             float* gm = ws->gmax.as<float>() + (int64_t)c0 * n_groups;
             hipError_t e;
             if (pass256)
-                e = use_qreg ? launch_scan_qreg_g(h, s, qf, d_mask, gm, nq, n_super)
-                             : launch_scan_gemm_g<16>(h, s, qf, d_mask, gm, nq, n_super);
+                e = (use_qreg && (g_dense_kernels & 16)) ? launch_scan_q64_g(h, s, qf, d_mask, gm, nq, n_super)
+                    : use_qreg ? launch_scan_qreg_g(h, s, qf, d_mask, gm, nq, n_super)
+                               : launch_scan_gemm_g<16>(h, s, qf, d_mask, gm, nq, n_super);
             else if (big)
                 e = (h->dtype == HR_F16) ? launch_scan_bigq_g<_Float16>(h, s, qf, d_mask, gm, nq, n_super)
                                          : launch_scan_bigq_g<float>(h, s, qf, d_mask, gm, nq, n_super);
@@ -1819,7 +1843,7 @@ int hr_debug_option(hr_index* h, int key, int value) {
             g_finish_mode = value;
             return HR_OK;
         case HR_DEBUG_DENSE_KERNELS:
-            if (value < 0 || value > 15) return fail(h, HR_EINVAL, "dense kernel mask must be 0..15");
+            if (value < 0 || value > 31) return fail(h, HR_EINVAL, "dense kernel mask must be 0..31");
             g_dense_kernels = value;
             return HR_OK;
         case HR_DEBUG_SPARSE_RPB:

@@ -402,7 +402,8 @@ HR_API int hr_set_scan_cus(hr_index* h, int n_cus);
  *   finalize after that must complete the build.
  * HR_DEBUG_DENSE_KERNELS (process-wide): bit mask that takes dense scan kernels out of the selection so that the
  *   others serve the shapes they would have served — 1 = no register-resident 256-query pass, 2 = no tiled-contraction
- *   pass, 4 = no k-chunked large-batch pass, 8 = prefer the tiled contraction where both 256-query passes apply.
+ *   pass, 4 = no k-chunked large-batch pass, 8 = prefer the tiled contraction where both 256-query passes apply, 16 = the 4 x 64-query register form
+ *   (dense_scan_q64_kernel) instead of the 8 x 32-query one for the 256-query pass at D = 768.
  * HR_DEBUG_SPARSE_RPB (process-wide): doc ranges one sparse-scan block walks (0 = by shard size).
  * HR_DEBUG_GROUP_ROWS (process-wide): rows per candidate group (16 or 64; 0 = by shard size) of handles created
  *   afterwards.

@@ -5,11 +5,14 @@ import torch
 sys.path.insert(0, "advanced-rag-milvus_amd"); sys.path.insert(0, ".")
 from advanced_rag import _native as nat
 import oracle
+nat.debug_option(nat.HR_DEBUG_DENSE_KERNELS, int(os.environ.get('PROBE_DENSE_MASK', '0')))
+nat.debug_option(nat.HR_DEBUG_GROUP_ROWS, int(os.environ.get('PROBE_GROUP_ROWS', '0')))   # 16 / 64 rows per candidate group (0 = by shard size)
+   # e.g. 16 = the 4 x 64-query register form
 
 # parity first (small corpus, B=200 -> GQ=16; B=100 -> GQ=8)
 rng = np.random.default_rng(0)
 for dt, npdt in (() if os.environ.get('SKIP_PARITY') else ((nat.HR_F16, np.float16), (nat.HR_F32, np.float32))):
-    for n, D in ((5000, 256), (70000, 256), (3333, 768), (70001, 768), (40000, 1024), (250000, 768)):
+    for n, D in (((3333, 768), (70001, 768)) if os.environ.get('PARITY_768') else ((5000, 256), (70000, 256), (3333, 768), (70001, 768), (40000, 1024), (250000, 768))):
         X = rng.standard_normal((n, D)).astype(np.float32).astype(npdt)
         X[n // 2] = X[7]  # a tie
         h = nat.ShardHandle(D, dt, nat.HR_METRIC_COSINE); h.add_dense(X); h.finalize()
