@@ -162,9 +162,11 @@ def step_hbm(rows: int, dim: int, batch: int, n_gpus: int, dist: str, use_sparse
             "frac_of_measured_copy": gbps / HBM_COPY_GBPS, "traffic_source": src}
 
 
-def scan_kernel_name(B: int, dim: int) -> str:
-    """Which dense scan serves a batch of B queries (dense_search_enqueue in csrc/hbmrag.hip)."""
+def scan_kernel_name(B: int, dim: int, mask: int = 0) -> str:
+    """Which dense scan serves a batch of B queries (dense_search_enqueue in csrc/hbmrag.hip); mask = --dense-kernel-mask."""
     kt = -(-(-(-dim // 32)) // 4) * 4          # 1 KiB tiles per row, padded to a multiple of 4
+    if B > 128 and kt == 24 and (mask & 16) and not (mask & 1):
+        return "dense_scan_q64_kernel<KT=24> (256 queries per pass: 4 waves x 64 queries in the unified register file)"
     if B > 128 and kt == 24:
         return "dense_scan_qreg_kernel<KT=24,GW=2,NW=8> (256 queries per pass)"
     if B > 128 and kt >= 8:
@@ -686,7 +688,7 @@ def main():
                        **({"simulate_ranks": sim, "projection": f"per-rank step of a {N * sim}-row corpus on {sim} GPUs: the merge of {sim} lists per modality "
                            "runs on the finishing stream, the all-gather itself is NOT included"} if sim else {}),
                        "parallelism": f"row-sharded x{world}, one RCCL all-gather of per-shard top-k' per step" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": scan_kernel_name(B, D), "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": scan_kernel_name(B, D, args.dense_kernel_mask), "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy": achieved / HBM_COPY_GBPS,
                          "traffic": traffic,
                          "traffic_source": traffic_src,
