@@ -426,7 +426,9 @@ def test_bench_step_hbm_sums_the_committed_pmc_traffic_of_every_search_kernel():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     # the NEWEST collection of the workload is the one consulted (an older round's file lists kernels that no longer run)
-    k = json.load(open(os.path.join(root, "profiles", "r3_pmc_traffic.json")))["kernels"]
+    import glob
+    newest = sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc_traffic.json")))[-1]     # the default workload's collections
+    k = json.load(open(newest))["kernels"]
     assert "finish_fused" in k and "refine_dense" not in k
     want = sum(k[name]["hbm_bytes_per_launch"] for name in mod.STEP_KERNELS if name in k)
     got = mod.step_hbm(10_000_000, 768, 128, 1, "uniform", True, 4.0)
