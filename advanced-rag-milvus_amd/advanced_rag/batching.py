@@ -109,6 +109,10 @@ class SearchCoalescer:
         # torchrun form (shards.CollectiveShardSet): a round of the front = one round of the shard set, i.e. ONE
         # broadcast + ONE gather for all the dense and sparse searches that share (top_k, filter, drop ratio)
         self.collective = hasattr(getattr(manager, "_main", None), "round")
+        if self.collective:
+            # a round of the torchrun form costs a broadcast + a gather over every rank whatever it carries: waiting a few
+            # hundred microseconds for the other search of the same retrieve() (and for other callers) halves the collectives
+            self.window_s = max(self.window_s, 250e-6)
         self.stats = {"rounds": 0, "requests": 0, "dense_launches": 0, "sparse_launches": 0, "fuse_launches": 0,
                       "hybrid_launches": 0, "encode_launches": 0, "encoded_texts": 0, "max_batch_seen": 0, "redone_unproven": 0,
                       "busy_s": 0.0}

@@ -38,6 +38,7 @@ from . import filters as _filters
 from .columns import FLOAT_COLUMNS, PayloadColumns
 from .constants import IndexingConstants
 from .embedding_cache import get_semantic_cache
+from ._native import HR_MAX_TOPK   # importing the binding module does not load the library
 from .shards import PartialAppend, ShardSet
 
 logger = logging.getLogger(__name__)
@@ -170,13 +171,17 @@ class MilvusIndexManager:
             self.collections["domain_index"] = ShardCollection(self, "domain_index", "dense", self._domain,
                                                                self.domain_dim, "COSINE")
 
-    def attach_shards(self, handles, rows_of=None, synthetic_rows: int = 0, process_group=None, first_row: int = 0):
+    def attach_shards(self, handles, rows_of=None, synthetic_rows: int = 0, process_group=None, first_row: int = 0,
+                      local_ids: bool = False):
         """Adopt already-built shard handles as the semantic (+ sparse) collection — e.g. the shard a benchmark has
         just filled.  rows_of[s] = global row of every local row of shard s (default: shard s follows shard s-1).
 
         With `process_group` (torch.distributed, one process per GPU) the collection spans the group's ranks: this
         rank's handle holds global rows [first_row, first_row + its rows) and must carry that offset
-        (ShardHandle.set_row_offset); rank 0 answers `search`/`retrieve`, the other ranks call `serve()`."""
+        (ShardHandle.set_row_offset); rank 0 answers `search`/`retrieve`, the other ranks call `serve()`.  With
+        `local_ids=True` the handle numbers its rows from 0 (rows_of[0] = their global rows; empty at the start) and
+        the collection is FILLED through rank 0: index_chunks / add_rows / add_rows_synthetic, finalize and
+        save_snapshot on rank 0 become collective operations the serving ranks take part in (shards.py)."""
         if not hasattr(self, "_native"):
             self._connect()
         handles = list(handles)
@@ -194,7 +199,7 @@ class MilvusIndexManager:
             if len(handles) != 1:
                 raise ValueError("the torchrun form takes one shard handle per process")
             group = None if process_group is True else process_group
-            self._main = CollectiveShardSet(local, first_row, dist, group)
+            self._main = CollectiveShardSet(local, first_row, dist, group, local_ids=local_ids)
         else:
             self._main = local
         self.devices = [h.device for h in handles]
@@ -466,7 +471,11 @@ class MilvusIndexManager:
             raise ValueError("shard is in synthetic-payload mode; use add_rows_synthetic")
         n = dense.shape[0]
         base = self.num_rows
-        _, _, sparse_err = self._main.add(dense, sparse_csr if "sparse_index" in self.collections else None)
+        failed = None
+        try:
+            _, _, sparse_err = self._main.add(dense, sparse_csr if "sparse_index" in self.collections else None)
+        except PartialAppend as pa:    # the shards numbered pa.end - pa.base rows: their payload goes in, then the caller hears
+            n, failed, sparse_err = pa.end - pa.base, pa.cause, None
         c = self._cols
         defaults = {"doc_id": lambda r: f"doc{r // 10}", "chunk_index": lambda r: r % 10, "token_count": lambda r: 0,
                     "entropy": lambda r: 0.0, "redundancy": lambda r: 0.0, "domain_density": lambda r: 0.0,
@@ -481,6 +490,8 @@ class MilvusIndexManager:
                 c[name].extend(given[lo:hi] if given is not None else [fn(base + r) for r in range(lo, hi)])
         self._mask_cache.clear()
         self._dev_masks.clear()
+        if failed is not None:
+            raise failed
         if sparse_err is not None:  # the rows are in (with empty sparse rows); the caller still hears about it
             raise sparse_err
 
@@ -489,11 +500,17 @@ class MilvusIndexManager:
         number on demand (10M-row benchmarks would otherwise hold GBs of Python strings)."""
         if len(self._cols["id"]):
             raise ValueError("shard already holds payload columns")
-        _, _, sparse_err = self._main.add(dense, sparse_csr if "sparse_index" in self.collections else None)
-        self._synthetic_rows += dense.shape[0]
+        n, failed = dense.shape[0], None
+        try:
+            _, _, sparse_err = self._main.add(dense, sparse_csr if "sparse_index" in self.collections else None)
+        except PartialAppend as pa:
+            n, failed, sparse_err = pa.end - pa.base, pa.cause, None
+        self._synthetic_rows += n
         self._dev_filters = None
         self._dev_masks.clear()
         self._mask_cache.clear()
+        if failed is not None:
+            raise failed
         if sparse_err is not None:
             raise sparse_err
 
@@ -543,6 +560,34 @@ class MilvusIndexManager:
         self._dev_filters = None
         self._mask_cache.clear()
         self._dev_masks.clear()
+
+    def load_snapshot_rank(self, directory: str, process_group=True, device: Optional[int] = None) -> None:
+        """Resume the torchrun form from a snapshot rank 0 wrote with save_snapshot(): EVERY rank calls this — it loads
+        its own shard file main.<rank>.hbmrag and its row map, rank 0 also the payload columns — then ranks > 0 serve()."""
+        import torch.distributed as dist
+        if not hasattr(self, "_native"):
+            self._connect()
+        nat = self._native
+        group = None if process_group is True else process_group
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        store = nat.HR_F16 if self.dtype in ("float16", "fp16", "f16") else nat.HR_F32
+        with np.load(os.path.join(directory, "payload.npz"), allow_pickle=False) as z:
+            if int(z["n_shards"]) != world:
+                raise ValueError(f"snapshot has {int(z['n_shards'])} shards, the process group has {world} ranks")
+            rows = z[f"rows_main_{rank}"].astype(np.int64)
+            sparse_on = os.getenv("ENABLE_SPARSE", "1") == "1"
+            dev = self.devices[0] if device is None else device
+            h = nat.ShardHandle.load(os.path.join(directory, f"main.{rank}.hbmrag"), self.semantic_dim, store,
+                                     nat.HR_METRIC_COSINE, self.sparse_dim if sparse_on else 0, dev)
+            synthetic = int(z["synthetic_rows"])
+            if rank == 0:
+                self._deleted = z["deleted"].copy() if z["deleted"].size else None
+                self._cols = PayloadColumns()
+                for k in self._cols:
+                    self._cols[k].extend(z[f"col_{k}"].tolist())
+        if self._main is not None:
+            self._main.close()
+        self.attach_shards([h], rows_of=[rows], synthetic_rows=synthetic, process_group=process_group, local_ids=True)
 
     # ------------------------------------------------------------------ search
     @staticmethod
@@ -718,7 +763,7 @@ class MilvusIndexManager:
         when this manager cannot answer that way (no front, sharded collection, a list the device form could not prove
         exact, bad parameters ...) — the caller then takes the general path, which also owns the error behaviour."""
         sem, spa = self.collections.get("semantic_index"), self.collections.get("sparse_index")
-        if sem is None or spa is None or sem.handle is not spa.handle or 2 * int(top_k) > self._native.HR_MAX_TOPK:
+        if sem is None or spa is None or sem.handle is not spa.handle or 2 * int(top_k) > HR_MAX_TOPK:
             return None
         front = self._coalescer(sem)
         if front is None or front.collective:

@@ -259,20 +259,30 @@ class CollectiveShardSet:
     collective.  Collectives are torch.distributed's (backend "nccl" = RCCL over xGMI on a GPU node; "gloo" in the CPU
     tests and one-GPU rehearsals); rounds are serialised by a lock, so every rank sees the same sequence.
 
-    The local shard must already carry its global row numbers (ShardHandle.set_row_offset(first_row)), i.e. a local
-    ShardSet of one handle; `first_row` says where this rank's rows sit in a global filter mask."""
+    Two forms of the local shard (a local ShardSet of one handle).  Pre-built: the rank filled its shard itself with one
+    contiguous global row range; the handle carries the numbers (ShardHandle.set_row_offset(first_row)) and `first_row`
+    says where the rank's rows sit in a global filter mask.  Ingested (`local_ids=True`): the handle numbers its rows from
+    0, `local.rows_of[0]` maps them to global rows, and the collection grows through the COLLECTIVE control operations —
+    add (the batch is broadcast, every rank keeps one contiguous block of it), finalize, save (every rank writes its own
+    shard file), row_maps (one gather) — which rank 0 calls while the other ranks sit in serve(); each is one control
+    packet + its payload broadcasts + one all-reduce of a status flag, so that rank 0 hears of a failure anywhere."""
 
-    OP_STOP, OP_ROUND = 0, 1
+    OP_STOP, OP_ROUND, OP_ADD, OP_FLUSH, OP_SAVE, OP_ROWMAPS = 0, 1, 2, 3, 4, 5
     HEADER = 16                     # int64 words
     PACKET_BYTES = 1 << 20          # header + queries of one round (128 x (768-d dense + 100-term sparse) = 0.5 MB)
     MAX_MASKS = 8
 
-    def __init__(self, local: ShardSet, first_row: int, dist, group=None, device=None):
+    def __init__(self, local: ShardSet, first_row: int, dist, group=None, device=None, local_ids: bool = False):
         import threading
 
         import torch
         self.torch, self.dist, self.group = torch, dist, group
         self.local, self.first_row = local, int(first_row)
+        # local_ids: the local handle numbers its rows from 0 and `local.rows_of[0]` says which global row each one is — the
+        # form a collection INGESTED through this set takes (round 4: `add` is collective, every batch is cut into one
+        # block per rank, so a rank's rows are no longer one contiguous global range).  Otherwise (a shard built by the rank
+        # itself, hr_set_row_offset(first_row)) the handle already returns global rows of a contiguous range.
+        self.local_ids = bool(local_ids)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.dev = torch.device(device) if device is not None else (
@@ -296,17 +306,152 @@ class CollectiveShardSet:
     num_sparse_rows = property(lambda self: self._n_sparse)
     rows_of = property(lambda self: self.local.rows_of)
 
-    def finalize(self):
-        self.local.finalize()
-
     def close(self):
         self.local.close()
 
+    def _global_rows(self) -> np.ndarray:
+        """Global row of every local row of this rank."""
+        if self.local_ids:
+            return self.local.rows_of[0]
+        return np.arange(self.first_row, self.first_row + max(self.local.num_rows, self.local.num_sparse_rows), dtype=np.int64)
+
+    # ------------------------------------------------------------------ collective control operations (rank 0 calls, the others serve())
+    def _control(self, op: int, words=(), blob: bytes = b""):
+        """rank 0: send a control packet (header words + an optional byte blob) — the workers pick it up in serve()."""
+        hdr = np.zeros(self.HEADER, dtype=np.int64)
+        hdr[0] = op
+        hdr[1: 1 + len(words)] = list(words)
+        hdr[self.HEADER - 1] = len(blob)
+        body = np.concatenate([hdr.view(np.uint8), np.frombuffer(blob, dtype=np.uint8)]) if blob else hdr.view(np.uint8)
+        if body.size > self.PACKET_BYTES:
+            raise ValueError("control packet too large")
+        return self._send_packet(body, whole=True)
+
+    def _status(self, err: Optional[Exception]):
+        """Every rank reports whether its part of a control operation worked; rank 0 raises if any did not."""
+        t = self.torch
+        flag = t.tensor([0 if err is None else 1], dtype=t.int64, device=self.dev)
+        self.n_collectives += 1
+        self.dist.all_reduce(flag, group=self.group)
+        if err is not None and self.rank != 0:
+            import logging
+            logging.getLogger(__name__).error("rank %d failed a collective control operation: %s", self.rank, err)
+        if self.rank == 0:
+            if err is not None:
+                raise err
+            if int(flag.item()):
+                raise RuntimeError("a collective control operation failed on another rank (see its log)")
+
+    def add(self, dense, sparse_csr=None, n: Optional[int] = None):
+        """Collective append (rank 0 calls it with the batch, the other ranks are in serve()): the batch travels in ONE
+        broadcast per part (dense rows, CSR), every rank keeps the contiguous block shard_range(n, rank, world) of it and
+        records which global rows those are (reference: Milvus spreads an insert over its `num_shards`,
+        indexing.py:234-239, :264-437).  Same return value as ShardSet.add.  Needs `local_ids`."""
+        if not self.local_ids:
+            raise RuntimeError("this shard set was attached with pre-built contiguous shards; collective ingest needs local_ids=True")
+        with self._lock:
+            if dense is not None and hasattr(dense, "detach"):
+                dense = dense.detach().float().cpu().numpy()
+            nrows = dense.shape[0] if dense is not None else (len(sparse_csr[0]) - 1 if sparse_csr is not None else int(n or 0))
+            dim = 0 if dense is None else int(dense.shape[1])
+            if sparse_csr is not None:      # positions from 0 and exactly nnz entries: the receivers size their buffers by it
+                ptr = np.asarray(sparse_csr[0], dtype=np.int64)
+                sparse_csr = (ptr - ptr[0], np.asarray(sparse_csr[1])[ptr[0]:ptr[-1]], np.asarray(sparse_csr[2])[ptr[0]:ptr[-1]])
+            nnz = 0 if sparse_csr is None else int(sparse_csr[0][-1])
+            self._control(self.OP_ADD, (nrows, dim, 1 if dense is not None else 0, 1 if sparse_csr is not None else 0, nnz))
+            return self._add_collective(nrows, dim, dense is not None, sparse_csr is not None, nnz, dense, sparse_csr)
+
+    def _add_collective(self, nrows, dim, has_dense, has_sparse, nnz, dense=None, sparse_csr=None):
+        from .engine import shard_range
+        t = self.torch
+
+        def bcast_array(arr, count, dtype):
+            buf = (t.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).to(self.dev) if self.rank == 0
+                   else t.empty(count, dtype=getattr(t, np.dtype(dtype).name), device=self.dev))
+            return self._bcast(buf.reshape(-1)).cpu().numpy()
+
+        err, out = None, (0, 0, None)
+        try:
+            d = bcast_array(dense, nrows * dim, np.float32).reshape(nrows, dim) if has_dense else None
+            csr = None
+            if has_sparse:
+                ptr = bcast_array(sparse_csr[0] if self.rank == 0 else None, nrows + 1, np.int64)
+                idx = bcast_array(sparse_csr[1] if self.rank == 0 else None, nnz, np.int32) if nnz else np.zeros(0, np.int32)
+                val = bcast_array(sparse_csr[2] if self.rank == 0 else None, nnz, np.float32) if nnz else np.zeros(0, np.float32)
+                csr = (ptr, idx, val)
+            lo, hi = shard_range(nrows, self.rank, self.world)
+            base = self._n_rows if has_dense or not has_sparse else self._n_sparse
+            # the global row numbers are taken on every rank BEFORE the local append: a rank whose append fails leaves a
+            # hole (rows no search returns) instead of ranks that disagree about the numbering
+            if has_dense or not has_sparse:
+                self._n_rows += nrows
+            if has_sparse or not has_dense:
+                self._n_sparse += nrows
+            self._masks.clear()          # row slices of cached filters are stale on every rank
+            self._mask_ids.clear()
+            sparse_err = None
+            if hi > lo:
+                piece_csr = None if csr is None else (csr[0][lo:hi + 1], csr[1], csr[2])
+                b0 = self.local._n
+                _, _, sparse_err = self.local.add(None if d is None else d[lo:hi], piece_csr, hi - lo)
+                self.local.rows_of[0][b0:] = np.arange(base + lo, base + hi, dtype=np.int64)   # global rows of the block
+            out = (base, base + nrows, sparse_err)
+        except Exception as e:
+            err = e
+        try:
+            self._status(err)
+        except Exception as e:
+            # the row numbers [base, base + nrows) are taken on every rank whatever failed: the caller keeps its payload
+            # columns aligned with them (the failing rank's block stays a hole no search returns)
+            base = out[0] if err is None else (self._n_rows if has_dense or not has_sparse else self._n_sparse) - nrows
+            raise PartialAppend(base, base + nrows, e) from e
+        return out
+
+    def finalize(self):
+        """Flush every rank's shard (rank 0 calls it; a rank in serve() flushes when the packet arrives)."""
+        if self.rank != 0 or not self.local_ids:
+            self.local.finalize()
+            return
+        with self._lock:
+            self._control(self.OP_FLUSH)
+            self._flush_collective()
+
+    def _flush_collective(self):
+        err = None
+        try:
+            self.local.finalize()
+        except Exception as e:
+            err = e
+        self._status(err)
+
     def save(self, path_of_shard) -> None:
-        raise NotImplementedError("snapshots of the torchrun form: save each rank's local shard (manager._main.local.save)")
+        """Every rank writes its shard to path_of_shard(rank) (rank 0 calls it; the paths travel in the control packet)."""
+        with self._lock:
+            paths = "\n".join(path_of_shard(r) for r in range(self.world)).encode("utf-8")
+            self._control(self.OP_SAVE, (), paths)
+            self._save_collective(paths)
+
+    def _save_collective(self, paths: bytes):
+        err = None
+        try:
+            mine = paths.decode("utf-8").split("\n")[self.rank]
+            self.local.save(lambda s: mine)
+        except Exception as e:
+            err = e
+        self._status(err)
 
     def row_maps(self):
-        raise NotImplementedError("the torchrun form keeps one contiguous row range per rank, not row maps")
+        """The global rows every rank's shard holds, in rank order (rank 0 calls it: one gather)."""
+        with self._lock:
+            self._control(self.OP_ROWMAPS)
+            return self._rowmaps_collective()
+
+    def _rowmaps_collective(self):
+        rows = self._global_rows()
+        parts = [None] * self.world if self.rank == 0 else None
+        self.n_collectives += 1
+        self.dist.gather_object(rows, parts, dst=0, group=self.group)
+        return [np.asarray(r, dtype=np.int64) for r in parts] if self.rank == 0 else None
 
     # ------------------------------------------------------------------ protocol
     def _bcast(self, t):
@@ -353,7 +498,7 @@ class CollectiveShardSet:
             raise ValueError(f"a round of {Bd} dense + {Bs} sparse queries needs {body.size} bytes; the packet holds {self.PACKET_BYTES}")
         return body, mask_bytes
 
-    def _send_packet(self, body: Optional[np.ndarray]):
+    def _send_packet(self, body: Optional[np.ndarray], whole: bool = False):
         """ONE broadcast of the fixed-size packet; returns its bytes as numpy on every rank."""
         t = self.torch
         if self.rank == 0:
@@ -364,6 +509,8 @@ class CollectiveShardSet:
         if self.rank == 0:
             return host
         hdr = self._packet[: self.HEADER * 8].cpu().numpy().view(np.int64)   # then only the bytes the round uses
+        if int(hdr[0]) != self.OP_ROUND:                                      # a control packet: header + its blob
+            return self._packet[: self.HEADER * 8 + int(hdr[self.HEADER - 1])].cpu().numpy()
         need = self.HEADER * 8 + int(hdr[1]) * int(hdr[4]) * 4 + (int(hdr[2]) + 1) * 8 * (1 if hdr[2] else 0) + int(hdr[5]) * 8
         return self._packet[: min(need, self.PACKET_BYTES)].cpu().numpy()
 
@@ -376,12 +523,12 @@ class CollectiveShardSet:
         if mask_new:
             buf = t.from_numpy(mask_bytes_rank0).to(self.dev) if self.rank == 0 else t.empty(mask_len, dtype=t.uint8, device=self.dev)
             bits = np.unpackbits(self._bcast(buf).cpu().numpy(), bitorder="little").astype(bool)
-            n_local = max(self.local.num_rows, self.local.num_sparse_rows)
-            if bits.size < self.first_row + n_local:
-                raise ValueError(f"filter mask covers {bits.size} rows, this rank holds rows up to {self.first_row + n_local}")
+            rows = self._global_rows()
+            if rows.size and bits.size <= int(rows.max()):
+                raise ValueError(f"filter mask covers {bits.size} rows, this rank holds rows up to {int(rows.max()) + 1}")
             if len(self._masks) >= self.MAX_MASKS:
                 self._masks.pop(next(iter(self._masks)))
-            self._masks[mask_id] = bits[self.first_row: self.first_row + n_local]
+            self._masks[mask_id] = bits[rows]
         return self._masks[mask_id]
 
     def _local_round(self, pkt: np.ndarray, hdr, keep_local):
@@ -394,7 +541,8 @@ class CollectiveShardSet:
         if Bd:
             q = pkt[off: off + Bd * dim * 4].view(np.float32).reshape(Bd, dim)
             off += Bd * dim * 4
-            kd = None if keep_local is None else keep_local[: self.local.num_rows]
+            # the slice object itself when it fits: the local ShardSet keeps a filter's packed (device) mask by identity
+            kd = None if keep_local is None else (keep_local if keep_local.size == self.local.num_rows else keep_local[: self.local.num_rows])
             if Bs:   # both modalities in the round: the dense search runs beside the sparse one (ctypes releases the GIL)
                 if self._side is None:
                     self._side = ThreadPoolExecutor(max_workers=1, thread_name_prefix="round-dense-")
@@ -409,7 +557,8 @@ class CollectiveShardSet:
             off += nnz * 4
             val = pkt[off: off + nnz * 4].view(np.float32)
             queries = [(idx[ptr[b]:ptr[b + 1]], val[ptr[b]:ptr[b + 1]]) for b in range(Bs)]
-            ks = None if keep_local is None else keep_local[: self.local.num_sparse_rows]
+            ks = None if keep_local is None else (keep_local if keep_local.size == self.local.num_sparse_rows
+                                                  else keep_local[: self.local.num_sparse_rows])
             try:
                 out.append(self.local.search_sparse(queries, k, drop, ks))
             finally:
@@ -419,6 +568,9 @@ class CollectiveShardSet:
                 if dense_err is not None:
                     raise dense_err
                 out[0] = dense_job.result()
+        if self.local_ids:
+            rows = self.local.rows_of[0]
+            out = [(np.where(li >= 0, rows[np.maximum(li, 0)] if rows.size else -1, -1).astype(np.int64), sc) for li, sc in out]
         return out
 
     def _round(self, body, mask_bytes):
@@ -428,6 +580,17 @@ class CollectiveShardSet:
         hdr = pkt[: self.HEADER * 8].view(np.int64)
         if int(hdr[0]) == self.OP_STOP:
             return False
+        if int(hdr[0]) != self.OP_ROUND:     # a worker picked up a control operation of rank 0
+            op = int(hdr[0])
+            if op == self.OP_ADD:
+                self._add_collective(int(hdr[1]), int(hdr[2]), bool(hdr[3]), bool(hdr[4]), int(hdr[5]))
+            elif op == self.OP_FLUSH:
+                self._flush_collective()
+            elif op == self.OP_SAVE:
+                self._save_collective(pkt[self.HEADER * 8: self.HEADER * 8 + int(hdr[self.HEADER - 1])].tobytes())
+            elif op == self.OP_ROWMAPS:
+                self._rowmaps_collective()
+            return True
         Bd, Bs, k = int(hdr[1]), int(hdr[2]), int(hdr[3])
         n_vals = (Bd + Bs) * k
         mine = np.zeros(2 + 2 * n_vals, dtype=np.int64)
