@@ -98,6 +98,22 @@ __device__ inline float col4_sum(float v) {
     return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 
+// Maximum over the 64 lanes with DPP row shifts / broadcasts (VALU only: each __shfl_xor step of wave_max below is a
+// ds_bpermute, ~100 cycles of LDS latency); the result is uniform (read from lane 63).
+__device__ inline float wave_max_dpp(float v) {
+#define HR_DPP_MAX(ctrl, rows)                                                                                      \
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v),                  \
+                                                                        __builtin_bit_cast(int, v), ctrl, rows, 0xf, false)))
+    HR_DPP_MAX(0x111, 0xf);   // row_shr:1   (lanes without a source keep v)
+    HR_DPP_MAX(0x112, 0xf);   // row_shr:2
+    HR_DPP_MAX(0x114, 0xf);   // row_shr:4
+    HR_DPP_MAX(0x118, 0xf);   // row_shr:8  -> lane 15 of each row holds the row's maximum
+    HR_DPP_MAX(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+    HR_DPP_MAX(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef HR_DPP_MAX
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 __device__ inline float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));

@@ -51,13 +51,15 @@ struct FinishPair {
 
 // LDS the kernel needs beyond its static arrays: the keys of every candidate row, then a region that first holds the
 // query's bucket maxima and later (sparse) the staged query and its membership filter.
+__host__ __device__ inline bool finish_sparse_hashed(int q_cap) { return q_cap <= kHashMaxTerms; }
 inline size_t finish_lds_bytes(const FinishPair& p) {
     size_t region_b = 0;
     for (int i = 0; i < p.n; ++i) {
         const FinishMod& m = p.m[i];
         if (m.sel.two_level) region_b = region_b > (size_t)m.sel.n_buckets * 4 ? region_b : (size_t)m.sel.n_buckets * 4;
         if (m.kind == 1) {
-            const size_t s = (size_t)kFilterBits / 8 + (size_t)m.q_cap * 8;
+            const size_t s = (size_t)kFilterBits / 8 +
+                             (finish_sparse_hashed(m.q_cap) ? (size_t)sparse_hash_slots(m.q_cap) * 8 : (size_t)m.q_cap * 8);
             region_b = region_b > s ? region_b : s;
         } else {
             const size_t s = (size_t)m.dim * 4;   // the query, staged for the refine
@@ -70,6 +72,8 @@ inline size_t finish_lds_bytes(const FinishPair& p) {
 // Bucket maxima of one query into LDS (what bucket_max_kernel writes to the global table).  A wave takes
 // kFinishBucketsPerWave buckets per trip and issues all their (coalesced, 256-byte) loads before the first reduction:
 // with 8 waves per block the pass is bound by memory latency, not bytes (312 KB per query at 1.25M rows).
+// (64 buckets per trip — 16 KiB in flight per wave — leave the phase as long as it is alone and cost the step 4 % in the
+// pipeline: 88 instead of 80 registers per lane beside the scan's waves; profiles/r4_experiments/finish_variants_ab.txt)
 constexpr int kFinishBucketsPerWave = 32;
 __device__ inline void bucket_max_block(const GroupSelArgs& a, int q, float* s_bmax) {
     const int lane = threadIdx.x & 63;
@@ -85,7 +89,7 @@ __device__ inline void bucket_max_block(const GroupSelArgs& a, int q, float* s_b
         float mine = -__builtin_inff();
 #pragma unroll
         for (int i = 0; i < kFinishBucketsPerWave; ++i) {
-            const float m = wave_max(v[i]);
+            const float m = wave_max_dpp(v[i]);
             if (lane == i) mine = m;
         }
         if (lane < kFinishBucketsPerWave && b0 + lane < a.n_buckets) s_bmax[b0 + lane] = mine;
@@ -125,6 +129,12 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
     const int n_live_slots = min(sh.n_live, a.sel.C) * a.group_rows;
     for (int slot = n_live_slots + tid; slot < n_slots; slot += kFinishThreads) s_key[slot] = 0ull;
     FINISH_STAMP(2);
+#ifdef HR_STAMP
+    if (blockIdx.x == 0 && tid == 0) {
+        hr_finish_stamps[blockIdx.y][5] = (unsigned long long)n_live_slots;
+        hr_finish_stamps[blockIdx.y][6] = 0ull;
+    }
+#endif
 
     if (a.kind == 0) {
         // the query in LDS (the bucket maxima are no longer needed): 64 query values per round as LDS reads instead of
@@ -134,6 +144,9 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
         __syncthreads();
         const double qn2 = a.qn2[q];
         for (int slot = tid; slot < n_live_slots; slot += kFinishThreads) {
+#ifdef HR_STAMP
+            if (blockIdx.x == 0) atomicAdd(&hr_finish_stamps[blockIdx.y][6], 1ull);   // rows that take the canonical chain
+#endif
             float sc = 0.f;
             int32_t row = -1;
             const bool ok = a.dtype == HR_F16
@@ -144,19 +157,38 @@ __global__ __launch_bounds__(kFinishThreads) void finish_kernel(FinishPair p) {
             s_key[slot] = ok ? rank_key(sc, (uint32_t)row) : 0ull;
         }
     } else {
-        unsigned int* s_filter = reinterpret_cast<unsigned int*>(s_bmax);  // the bucket maxima are no longer needed
-        int32_t* s_idx = reinterpret_cast<int32_t*>(s_filter + kFilterBits / 32);
-        float* s_val = reinterpret_cast<float*>(s_idx + a.q_cap);
-        const int nt = refine_sparse_stage_query(a.q_indptr, a.q_idx, a.q_val, q, a.q_cap, s_filter, s_idx, s_val);
-        const int n_chains = (n_live_slots + 63) / 64;
+        // the docs in chains of equal length, a multiple of 8 of them: every wave walks the same number of docs (chains of
+        // 64 left half of the waves with twice the docs of the others whenever the trim kept 9 .. 15 x 64 of them)
+        constexpr int NW = kFinishThreads / 64;
+        const int n_chains = NW * ((n_live_slots + NW * 64 - 1) / (NW * 64));
+        const int chain_len = (n_live_slots + n_chains - 1) / n_chains;
         const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-        for (int chain = wid; chain < n_chains; chain += kFinishThreads / 64) {
-            const int slot0 = chain * 64;
-            const int n_here = min(64, n_live_slots - slot0);
-            refine_sparse_chain(a.indptr, a.idx, a.val, a.rowmask, s_cand, a.group_rows, a.n_rows, slot0, n_here,
-                                s_filter, s_idx, s_val, nt, [&](int slot, bool keep, float score, int64_t doc) {
-                                    s_key[slot] = keep ? rank_key(score, (uint32_t)doc) : 0ull;
-                                });
+        auto emit = [&](int slot, bool keep, float score, int64_t doc) { s_key[slot] = keep ? rank_key(score, (uint32_t)doc) : 0ull; };
+        if (finish_sparse_hashed(a.q_cap)) {
+            const int hs = sparse_hash_slots(a.q_cap);
+            unsigned int* s_filter = reinterpret_cast<unsigned int*>(s_bmax);   // the bucket maxima are no longer needed
+            int32_t* s_hkey = reinterpret_cast<int32_t*>(s_filter + kFilterBits / 32);
+            float* s_hval = reinterpret_cast<float*>(s_hkey + hs);
+            refine_sparse_stage_query_hash(a.q_indptr, a.q_idx, a.q_val, q, a.q_cap, hs, s_filter, s_hkey, s_hval);
+            for (int chain = wid; chain < n_chains; chain += NW) {
+                const int slot0 = chain * chain_len;
+                const int n_here = min(chain_len, n_live_slots - slot0);
+                if (n_here > 0)
+                    refine_sparse_chain(a.indptr, a.idx, a.val, a.rowmask, s_cand, a.group_rows, a.n_rows, slot0, n_here,
+                                        SparseLookupHash{s_filter, s_hkey, s_hval, hs}, emit);
+            }
+        } else {
+            unsigned int* s_filter = reinterpret_cast<unsigned int*>(s_bmax);
+            int32_t* s_idx = reinterpret_cast<int32_t*>(s_filter + kFilterBits / 32);
+            float* s_val = reinterpret_cast<float*>(s_idx + a.q_cap);
+            const int nt = refine_sparse_stage_query(a.q_indptr, a.q_idx, a.q_val, q, a.q_cap, s_filter, s_idx, s_val);
+            for (int chain = wid; chain < n_chains; chain += NW) {
+                const int slot0 = chain * chain_len;
+                const int n_here = min(chain_len, n_live_slots - slot0);
+                if (n_here > 0)
+                    refine_sparse_chain(a.indptr, a.idx, a.val, a.rowmask, s_cand, a.group_rows, a.n_rows, slot0, n_here,
+                                        SparseLookupSorted{s_filter, s_idx, s_val, nt}, emit);
+            }
         }
     }
     __syncthreads();

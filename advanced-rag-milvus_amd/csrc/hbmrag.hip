@@ -594,8 +594,10 @@ int launch_refine_sparse(hr_index* h, Workspace* ws, hipStream_t s, const int64_
     // with 16) but the step does not gain — the kernel runs beside the scans, and what it takes from the HBM sooner they
     // get later (round 2 A/B).
     const int dpw = 64;
-    hipLaunchKernelGGL(refine_sparse_kernel, dim3((C * GR + 4 * dpw - 1) / (4 * dpw), B), dim3(256),
-                       (size_t)kFilterBits / 8 + (size_t)stride * 8, s, h->s_indptr.as<int64_t>(),
+    const bool hashed = stride <= kHashMaxTerms;   // the query's terms as a hash table behind the filter (sparse.h)
+    const size_t lds = (size_t)kFilterBits / 8 + (hashed ? (size_t)sparse_hash_slots(stride) * 8 : (size_t)stride * 8);
+    hipLaunchKernelGGL(hashed ? refine_sparse_kernel<true> : refine_sparse_kernel<false>,
+                       dim3((C * GR + 4 * dpw - 1) / (4 * dpw), B), dim3(256), lds, s, h->s_indptr.as<int64_t>(),
                        h->s_idx.as<int32_t>(), h->s_val.as<float>(), d_qptr, d_qidx, d_qval, d_mask,
                        ws->cand.as<int32_t>(), C, GR, h->n_sparse, stride, dpw, ws->cscore.as<float>(),
                        ws->crow.as<int32_t>());

@@ -29,6 +29,8 @@ __device__ inline void radix_pass(KeyFn key, int64_t n, uint64_t prefix, uint64_
                                   SelectScratch& sh) {
     for (int i = threadIdx.x; i < 256; i += blockDim.x) sh.hist[i] = 0;
     __syncthreads();
+    // (per-lane atomics: folding the lanes of a wave that share a digit into one add — the upper digits of a candidate set
+    // are nearly all equal — measured 10 % SLOWER, profiles/r4_experiments/finish_hashfilter_aggregated_*.txt)
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
         const uint64_t kk = key(i);
         if ((kk & mask) == prefix) atomicAdd(&sh.hist[(kk >> shift) & 255], 1u);
@@ -68,8 +70,10 @@ __device__ inline void radix_pass(KeyFn key, int64_t n, uint64_t prefix, uint64_
 // Requires 1 <= K <= n.  Four passes resolve the score; when exactly one key
 // carries that score (the usual case) it is fetched directly, otherwise four
 // more passes resolve the index bits among the ties.
+// score_only: stop after the four passes that resolve the upper 32 bits (the caller wants the K-th largest SCORE, its keys
+// need not be unique); the lower 32 bits of the result are zero.
 template <typename KeyFn>
-__device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, SelectScratch& sh) {
+__device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, SelectScratch& sh, bool score_only = false) {
     uint64_t prefix = 0, mask = 0;
     int remaining = K;
     int same = 0;
@@ -81,6 +85,7 @@ __device__ inline uint64_t block_kth_largest(KeyFn key, int64_t n, int K, Select
         same = sh.count;
         __syncthreads();
     }
+    if (score_only) return prefix;
     if (same == 1) {  // a single key has this score: find it
         for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
             const uint64_t kk = key(i);
@@ -162,6 +167,8 @@ __global__ __launch_bounds__(256) void bucket_max_kernel(GroupSelPair p) {
 // unselected bucket maximum, groups inside them by the (C+1)-th candidate key.
 // Block function (any block size that is a multiple of 64): `bm` = the bucket maxima of THIS query (global table row or
 // an LDS copy), `out` = the C candidate slots of this query (global or LDS).
+// (Staging the maxima of the selected buckets' groups in LDS once, instead of fetching them in each level-1 pass, did not
+// pay: the passes are bound by their LDS work and barriers, not by those L2 hits — profiles/r4_experiments/.)
 __device__ inline void select_groups_block(const GroupSelArgs& a, int q, const float* bm, int32_t* out,
                                            SelectScratch& sh, int32_t* sel_bucket) {
     const int64_t n_groups = a.n_groups, n_buckets = a.n_buckets;

@@ -626,14 +626,80 @@ __device__ inline int refine_sparse_stage_query(const int64_t* __restrict__ q_in
     return nt;
 }
 
+// The fused finishing kernel's form for queries of up to kHashMaxTerms terms: the same membership filter, and for the
+// entries that pass it an open-addressing hash table in LDS (keys s_hkey[hs], values s_hval[hs], hs a power of two >= 4 x
+// the terms: load <= 0.25, linear probing, -1 = empty) instead of the lower-bound search — one or two dependent LDS reads
+// where the search costs the wave ~7 as soon as ONE lane passes the filter.  A term that occurs twice in the query keeps
+// its FIRST value, as the search does.  (The hash alone, without the filter in front, lost: every lane probes, and the
+// longest probe sequence of 64 lanes is 3 - 4 reads — profiles/r4_experiments/finish_prerank_hash_*.txt.)
+constexpr int kHashMaxTerms = 256;
+__host__ __device__ inline int sparse_hash_slots(int q_cap) { return q_cap <= 128 ? 512 : 1024; }
+__device__ inline unsigned sparse_hash(int32_t t, int hs) { return ((unsigned)t * 0x9E3779B1u) >> (hs == 512 ? 23 : 22); }
+__device__ inline void refine_sparse_stage_query_hash(const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
+                                                      const float* __restrict__ q_val, int qi, int q_cap, int hs,
+                                                      unsigned int* s_filter, int32_t* s_hkey, float* s_hval) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int64_t t0 = q_indptr[qi];
+    const int nt = min((int)(q_indptr[qi + 1] - t0), q_cap);
+    for (int i = tid; i < kFilterBits / 32; i += nthr) s_filter[i] = 0u;
+    for (int i = tid; i < hs; i += nthr) s_hkey[i] = -1;
+    __syncthreads();
+    for (int i = tid; i < nt; i += nthr) {
+        const int32_t t = q_idx[t0 + i];
+        if (t < 0 || (i > 0 && q_idx[t0 + i - 1] == t)) continue;   // the terms are sorted: a repeat sits next to its first
+        atomicOr(&s_filter[(t & (kFilterBits - 1)) >> 5], 1u << (t & 31));
+        unsigned h = sparse_hash(t, hs);
+        while (atomicCAS(&s_hkey[h], -1, t) != -1) h = (h + 1) & (hs - 1);
+        s_hval[h] = q_val[t0 + i];
+    }
+    __syncthreads();
+}
+struct SparseLookupSorted {   // membership filter, then lower-bound search in the sorted terms
+    const unsigned int* s_filter;
+    const int32_t* s_idx;
+    const float* s_val;
+    int nt;
+    __device__ inline bool operator()(int32_t tt, float* qv) const {
+        if (!((s_filter[(tt & (kFilterBits - 1)) >> 5] >> (tt & 31)) & 1u)) return false;
+        int lo = 0, hi = nt;  // first position with s_idx[pos] >= tt
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_idx[mid] < tt) lo = mid + 1; else hi = mid;
+        }
+        if (lo < nt && s_idx[lo] == tt) {
+            *qv = s_val[lo];
+            return true;
+        }
+        return false;
+    }
+};
+struct SparseLookupHash {
+    const unsigned int* s_filter;
+    const int32_t* s_hkey;
+    const float* s_hval;
+    int hs;
+    __device__ inline bool operator()(int32_t tt, float* qv) const {
+        if (!((s_filter[(tt & (kFilterBits - 1)) >> 5] >> (tt & 31)) & 1u)) return false;
+        unsigned h = sparse_hash(tt, hs);
+        for (;;) {
+            const int32_t k = s_hkey[h];
+            if (k == tt) {
+                *qv = s_hval[h];
+                return true;
+            }
+            if (k == -1) return false;
+            h = (h + 1) & (hs - 1);
+        }
+    }
+};
+
 // One wave walks the n_here (<= 64) candidate doc slots slot0 .. slot0 + n_here - 1 of a query whose terms are staged in
-// LDS; emit(slot, keep, score, doc) is called once per slot by the lane that owns it.
-template <typename Emit>
+// LDS (`lookup`); emit(slot, keep, score, doc) is called once per slot by the lane that owns it.
+template <typename Lookup, typename Emit>
 __device__ inline void refine_sparse_chain(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
                                            const float* __restrict__ val, const uint8_t* __restrict__ rowmask,
                                            const int32_t* cand_q, int group_docs, int64_t n_docs, int slot0, int n_here,
-                                           const unsigned int* s_filter, const int32_t* s_idx, const float* s_val, int nt,
-                                           Emit emit) {
+                                           Lookup lookup, Emit emit) {
     const int lane = threadIdx.x & 63;
     // lane l describes doc slot0 + l
     const int slot = slot0 + lane;
@@ -675,19 +741,10 @@ __device__ inline void refine_sparse_chain(const int64_t* __restrict__ indptr, c
     };
     double s = 0.0;
     auto consume = [&](int32_t tt, float vv) {  // one entry per lane; adds the matches in lane (= entry) order
-        bool hit = false;
         double prod = 0.0;
-        if (tt >= 0 && ((s_filter[(tt & (kFilterBits - 1)) >> 5] >> (tt & 31)) & 1u)) {
-            int lo = 0, hi = nt;  // first position with s_idx[pos] >= tt
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (s_idx[mid] < tt) lo = mid + 1; else hi = mid;
-            }
-            if (lo < nt && s_idx[lo] == tt) {
-                hit = true;
-                prod = __dmul_rn((double)vv, (double)s_val[lo]);
-            }
-        }
+        float qv = 0.f;
+        const bool hit = tt >= 0 && lookup(tt, &qv);
+        if (hit) prod = __dmul_rn((double)vv, (double)qv);
         unsigned long long m = __ballot(hit);
         const unsigned long long pb = (unsigned long long)__double_as_longlong(prod);
         const int pl = (int)(unsigned int)pb, ph = (int)(unsigned int)(pb >> 32);
@@ -730,6 +787,7 @@ __device__ inline void refine_sparse_chain(const int64_t* __restrict__ indptr, c
     if (lane < n_here) emit(slot, valid && my_score > 0.f, my_score, doc);
 }
 
+template <bool HASH>
 __global__ __launch_bounds__(256) void refine_sparse_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, const float* __restrict__ val,
     const int64_t* __restrict__ q_indptr, const int32_t* __restrict__ q_idx,
@@ -740,22 +798,30 @@ __global__ __launch_bounds__(256) void refine_sparse_kernel(
     // longest query rounded up, so short queries leave the CU room for many blocks)
     extern __shared__ unsigned int refine_lds[];
     unsigned int* s_filter = refine_lds;
+    const int hs = sparse_hash_slots(q_cap);    // HASH: keys and values of the table instead of the sorted terms
     int32_t* s_idx = reinterpret_cast<int32_t*>(refine_lds + kFilterBits / 32);
-    float* s_val = reinterpret_cast<float*>(s_idx + q_cap);
+    float* s_val = reinterpret_cast<float*>(s_idx + (HASH ? hs : q_cap));
     const int qi = blockIdx.y, tid = threadIdx.x;
-    const int nt = refine_sparse_stage_query(q_indptr, q_idx, q_val, qi, q_cap, s_filter, s_idx, s_val);
+    int nt = 0;
+    if constexpr (HASH) refine_sparse_stage_query_hash(q_indptr, q_idx, q_val, qi, q_cap, hs, s_filter, s_idx, s_val);
+    else nt = refine_sparse_stage_query(q_indptr, q_idx, q_val, qi, q_cap, s_filter, s_idx, s_val);
     const int n_slots = C * group_docs;
     // A wave's docs are a serial chain (each waits for its entries): docs_per_wave (8..64, the host's choice) trades the
     // length of that chain against the number of blocks that rebuild the filter.
     const int slot0 = __builtin_amdgcn_readfirstlane((blockIdx.x * 4 + (tid >> 6)) * docs_per_wave);  // first doc slot of this wave
     if (slot0 >= n_slots) return;
     const int n_here = min(docs_per_wave, n_slots - slot0);
-    refine_sparse_chain(indptr, idx, val, rowmask, cand + (int64_t)qi * C, group_docs, n_docs, slot0, n_here, s_filter,
-                        s_idx, s_val, nt, [&](int slot, bool keep, float score, int64_t doc) {
-                            const int64_t o = (int64_t)qi * n_slots + slot;
-                            out_score[o] = keep ? score : -__builtin_inff();
-                            out_row[o] = keep ? (int32_t)doc : -1;
-                        });
+    auto emit = [&](int slot, bool keep, float score, int64_t doc) {
+        const int64_t o = (int64_t)qi * n_slots + slot;
+        out_score[o] = keep ? score : -__builtin_inff();
+        out_row[o] = keep ? (int32_t)doc : -1;
+    };
+    if constexpr (HASH)
+        refine_sparse_chain(indptr, idx, val, rowmask, cand + (int64_t)qi * C, group_docs, n_docs, slot0, n_here,
+                            SparseLookupHash{s_filter, s_idx, s_val, hs}, emit);
+    else
+        refine_sparse_chain(indptr, idx, val, rowmask, cand + (int64_t)qi * C, group_docs, n_docs, slot0, n_here,
+                            SparseLookupSorted{s_filter, s_idx, s_val, nt}, emit);
 }
 
 }  // namespace hbmrag

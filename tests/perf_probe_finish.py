@@ -1,7 +1,7 @@
 """Ad-hoc probe (not a test): where a block of the fused finishing kernel spends its time, alone on an idle chip.
     make -C advanced-rag-milvus_amd stamp
     HBMRAG_LIB=advanced-rag-milvus_amd/lib/libhbmrag_stamp.so python tests/perf_probe_finish.py [rows=1250000]
-s_memtime runs at 100 MHz: 1 tick = 10 ns.  Block (query 0, modality m) of the last launch."""
+s_memtime ticks are shader cycles here (~2.1 GHz under load).  Block (query 0, modality m) of the last launch."""
 import ctypes
 import os
 import sys
@@ -36,8 +36,26 @@ sc = torch.empty((2, B, kp), dtype=torch.float32, device=dev)
 fl = torch.empty((2, B), dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 h.hybrid_scan_dev(q.data_ptr(), dp.data_ptr(), di.data_ptr(), dv.data_ptr(), B, len(idx), mx, kp, 0, st)
+L = nat.load_library()
+fn = getattr(L, "hr_debug_finish_stamps", None)
+
+
+def stamps():
+    if fn is None:
+        print("not a stamp build: no phase shares")
+        return
+    buf = (ctypes.c_ulonglong * 16)()
+    fn(buf)
+    v = np.array(list(buf), dtype=np.int64).reshape(2, 8)
+    for m, label in ((0, "dense block"), (1, "sparse block")):
+        d = np.diff(v[m][:5]) * 1e-3
+        print(f"  {label}: {v[m][5]} candidate rows after the trim, {v[m][6]} through the canonical chain")
+        print(f"  {label}: bucket maxima {d[0]:.1f}, group select {d[1]:.1f}, refine {d[2]:.1f}, top-k {d[3]:.1f}, total {d.sum():.1f} (k shader cycles)")
+
+
 for mode, name in ((1, "chain"), (2, "fused")):
     nat.debug_option(nat.HR_DEBUG_FINISH_MODE, mode)
+
     for _ in range(3):
         h.hybrid_finish_dev(q.data_ptr(), dp.data_ptr(), di.data_ptr(), dv.data_ptr(), B, mx, kp, 0, ids.data_ptr(), sc.data_ptr(), fl.data_ptr(), st)
     torch.cuda.synchronize()
@@ -46,13 +64,5 @@ for mode, name in ((1, "chain"), (2, "fused")):
         h.hybrid_finish_dev(q.data_ptr(), dp.data_ptr(), di.data_ptr(), dv.data_ptr(), B, mx, kp, 0, ids.data_ptr(), sc.data_ptr(), fl.data_ptr(), st)
     torch.cuda.synchronize()
     print(f"{name}: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us per finish alone (B = {B}, rows = {N}); all proven: {int(fl.min()) == 1}")
-L = nat.load_library()
-fn = getattr(L, "hr_debug_finish_stamps", None)
-if fn is None:
-    sys.exit("not a stamp build: no phase shares")
-buf = (ctypes.c_ulonglong * 16)()
-fn(buf)
-v = np.array(list(buf), dtype=np.int64).reshape(2, 8)
-for m, label in ((0, "dense block"), (1, "sparse block")):
-    d = np.diff(v[m][:5]) * 0.01
-    print(f"{label}: bucket maxima {d[0]:.1f} us, group select {d[1]:.1f} us, refine {d[2]:.1f} us, top-k {d[3]:.1f} us, total {d.sum():.1f} us")
+    if mode == 2:
+        stamps()

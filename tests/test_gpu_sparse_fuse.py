@@ -267,3 +267,40 @@ def test_dense_run_format_boundaries_and_appends(gpu):
     oids, osc = oracle.sparse_search(ptr, idx, val, queries, 40, 0.0, mask)
     assert np.array_equal(ids, oids) and np.array_equal(_bits(sc), _bits(osc))
     h.close()
+
+
+def test_refine_lookup_forms_agree_with_the_oracle(gpu):
+    """The canonical sparse refine looks every doc entry up in the query: queries of up to 256 terms as a hash table behind
+    the membership filter (csrc/sparse.h SparseLookupHash), longer ones by a lower-bound search in the sorted terms.  Both
+    forms, both finishing paths (the fused kernel and the multi-launch chain), at the lengths either side of the table
+    sizes (128 | 129 terms: 512 -> 1024 slots; 256 | 257: table -> search) — ids and scores bit for bit.  (A term that
+    occurs twice in a query is refused at the boundary: "duplicate query index".)"""
+    rng = np.random.default_rng(77)
+    n, V, nnz = 30000, 4096, 40
+    idx = np.sort(np.argpartition(rng.random((n, V)), nnz - 1, axis=1)[:, :nnz], axis=1).astype(np.int32).reshape(-1)
+    val = np.abs(rng.standard_normal(n * nnz)).astype(np.float32) + 0.01
+    ptr = np.arange(n + 1, dtype=np.int64) * nnz
+    queries = []
+    for nt in (3, 128, 129, 256, 257, 600):
+        qi = np.sort(rng.choice(V, nt, replace=False)).astype(np.int32)
+        queries.append((qi, np.abs(rng.standard_normal(nt)).astype(np.float32) + 0.01))
+    # terms that collide in the 512-slot table (same upper hash bits): multiples of 2^23 / 0x9E3779B1 do not exist, so take
+    # what the hash gives: among 4096 terms many pairs share a slot — a 128-term query has ~14 occupied-slot collisions
+    qi = np.sort(rng.choice(V, 128, replace=False)).astype(np.int32)
+    queries.append((qi, np.abs(rng.standard_normal(128)).astype(np.float32) + 0.01))
+    h = nat.ShardHandle(0, sparse_dim=V)
+    h.add_sparse(ptr, idx, val)
+    h.finalize()
+    try:
+        for group in ([queries[0], queries[1], queries[6]], [queries[2], queries[3]], [queries[4], queries[5]], queries):
+            want_i, want_s = oracle.sparse_search(ptr, idx, val, group, 40, 0.0)
+            for mode in (1, 2):
+                nat.debug_option(nat.HR_DEBUG_FINISH_MODE, mode)
+                ids, sc = h.search_sparse(group, 40, 0.0)
+                assert np.array_equal(ids, want_i), (mode, len(group))
+                assert np.array_equal(_bits(sc), _bits(want_s)), (mode, len(group))
+        with pytest.raises(ValueError, match="duplicate query index"):
+            h.search_sparse([(np.array([7, 7, 9], np.int32), np.ones(3, np.float32))], 40, 0.0)
+    finally:
+        nat.debug_option(nat.HR_DEBUG_FINISH_MODE, 0)
+        h.close()
