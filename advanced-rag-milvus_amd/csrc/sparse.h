@@ -12,13 +12,21 @@ namespace hbmrag {
 
 constexpr int kRangeDocs = 16384;                     // docs per range = LDS accumulator length (u16 local ids)
 constexpr int kScanTermChunk = 256;                   // query terms staged per pass
-// A term that at least half of a range's docs have is stored as a DENSE run: one fp16 weight per doc of the range, in doc
-// order (kRangeDocs / 2 posting words; 0x8000 = the doc does not have the term), instead of a 4-byte posting per doc that
+// A term that at least half of a range's docs have is stored as a DENSE run: one fp16 weight per doc of the range, at
+// dense_run_pos(doc) (kRangeDocs / 2 posting words; 0x8000 = the doc does not have the term), instead of a 4-byte posting per doc that
 // has it — never longer than the sparse form, and the scan applies it without LDS atomics and without a slot table (the
 // thread that owns 32 consecutive docs adds the 32 products to its own accumulators).  On Zipfian postings these few runs are
 // most of a query's postings.  A run is dense iff its length is exactly kDenseRunWords: sparse runs are shorter.
 constexpr unsigned kDenseRunWords = kRangeDocs / 2;
 constexpr unsigned short kDenseAbsent = 0x8000u;      // -0.0: a stored weight of +/-0 is canonicalised to +0
+// Where local doc d sits inside a dense run (in fp16 units).  The scan thread that owns docs 32 t .. 32 t + 31 applies a run
+// as four 16-byte pieces (8 docs each); piece q of ALL 512 threads is stored contiguously, so a wave's load of its piece q
+// is one fully coalesced 1 KiB (in doc order a lane's piece sat 64 bytes from its neighbour's: sixteen 64-byte sectors
+// touched per 256 bytes used, four times over for the four pieces).
+__host__ __device__ inline unsigned dense_run_pos(unsigned local_doc) {
+    const unsigned t = local_doc >> 5, i = local_doc & 31u;
+    return (((i >> 3) * (unsigned)(kRangeDocs / 32) + t) << 3) | (i & 7u);
+}
 
 // ---- build: CSR (doc-major) -> range-major postings ---------------------------
 // rt_off[range][t] counts, then (after the per-range exclusive scan) offsets of
@@ -129,7 +137,7 @@ __global__ void sparse_fill_kernel(const int64_t* __restrict__ indptr, const int
         if (off[t + 1] - lo == kDenseRunWords) {   // dense run: the doc's weight at its own place (the block was preset to "absent")
             unsigned short hb = posting_weight_bits(val[e]);
             if (hb == kDenseAbsent) hb = 0;         // a stored -0 counts like +0 (one unit, as in the sparse form)
-            reinterpret_cast<unsigned short*>(post + base + lo)[local] = hb;
+            reinterpret_cast<unsigned short*>(post + base + lo)[dense_run_pos(local)] = hb;
         } else {
             unsigned int slot = atomicAdd(&cur[t], 1u);
             post[base + slot] = pack_posting(local, val[e]);
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
         const unsigned x = (T.e0[slot] + 4 * l16) * 2654435761u;
         return (u32x4_a4){(x >> 7 & 0x3FFFu) | 0x3C000000u, (x >> 11 & 0x3FFFu) | 0x3C000000u, (x >> 5 & 0x3FFFu) | 0x3C000000u, (x >> 13 & 0x3FFFu) | 0x3C000000u};
 #else
-        return *reinterpret_cast<const u32x4_a4*>(a);
+        return *reinterpret_cast<const u32x4_a4*>(a);   // (a non-temporal load here: 0.76 -> 0.91 ms, profiles/r4_experiments/sparse_layout_nt_probe.txt)
 #endif
     };
     auto apply_item = [&](const ScanTab& T, int item, const u32x4_a4& v) {
@@ -519,7 +527,7 @@ __global__ __launch_bounds__(kScanThreads, kScanThreads / 128) void sparse_scan_
             // four 16-byte pieces (the quarters of a run) in flight: quarter q of the next run is requested right after
             // quarter q of this one has been applied — the registers are the ones the posting pipeline gave up (kScanKDense)
             auto piece = [&](int d, int q) -> u32x4_a4 {
-                return *reinterpret_cast<const u32x4_a4*>(pp_c + dl_lo[ring][d] + 16 * tid + 4 * q);
+                return *reinterpret_cast<const u32x4_a4*>(pp_c + dl_lo[ring][d] + 4 * (q * kScanThreads + tid));   // dense_run_pos
             };
             u32x4_a4 r[4];
 #pragma unroll
