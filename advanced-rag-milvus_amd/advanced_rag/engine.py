@@ -460,6 +460,29 @@ class PipelinedSearchEngine(HybridSearchEngine):
         # optional callable(buffers) run on the light stream after fusion/rerank of every batch, before the
         # batch is marked done (e.g. a cross-encoder forward over the fused candidates)
         self.post_hook = None
+        # post_hook_exclusive: the hook is compute-bound work that gains nothing from sharing the chip with the HBM-bound scans
+        # (a cross-encoder forward beside the scans of the next batches: both slower, the step no shorter — DESIGN section 5).
+        # The hook of batch i is then enqueued when batch i + 1 is submitted: it waits for scan(i + 1), and scan(i + 2) waits
+        # for it, so a step is  forward + max(scans, finishing)  instead of everything sharing the chip.
+        self.post_hook_exclusive = False
+        self._pending_hook = None       # the batch whose hook has not been enqueued yet
+        self._hook_ev = None            # recorded behind the hook enqueued last
+
+    def _run_hook(self, b):
+        """Enqueue the post hook of batch b on the light stream (the caller has made the stream wait for what it must)."""
+        t = self.torch
+        with t.cuda.stream(self.light):
+            self.post_hook(b)
+            b["done"].record(self.light)
+            if self._hook_ev is None:
+                self._hook_ev = t.cuda.Event()
+            self._hook_ev.record(self.light)
+
+    def flush_hook(self):
+        """Enqueue the hook of the last submitted batch (exclusive mode defers it to the next submit)."""
+        if self._pending_hook is not None:
+            pb, self._pending_hook = self._pending_hook, None
+            self._run_hook(pb)
 
     def _slot(self, slot: int, B: int) -> dict:
         b = self._slot_bufs[slot].get(B)
@@ -494,23 +517,35 @@ class PipelinedSearchEngine(HybridSearchEngine):
             self.heavy.wait_event(b["prep_done"])
         else:
             self.heavy.wait_event(b["done"])
+        exclusive = self.post_hook is not None and self.post_hook_exclusive and self.depth >= 2   # (one slot: its buffers are reused at once)
+        if exclusive and self._hook_ev is not None:
+            self.heavy.wait_event(self._hook_ev)    # the hook enqueued last (batch i - 2) has the chip to itself
         self.h.hybrid_scan_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, nnz, int(max_nnz),
                                kp, slot, self.heavy.cuda_stream)
         with t.cuda.stream(self.heavy):
             self._search_domain(b, domain_q, B, self.heavy.cuda_stream)
         b["scan_done"].record(self.heavy)
         self.light.wait_event(b["scan_done"])
+        if not exclusive:
+            self.flush_hook()                       # (the mode was switched off with a hook still pending)
+        elif self._pending_hook is not None:
+            pb, self._pending_hook = self._pending_hook, None
+            self._run_hook(pb)                      # batch i - 1's hook: behind this batch's scan, before its finishing work
         with t.cuda.stream(self.light):
             self.h.hybrid_finish_dev(q.data_ptr(), indptr.data_ptr(), idx.data_ptr(), val.data_ptr(), B, int(max_nnz),
                                      kp, slot, b["ids"].data_ptr(), b["scores"].data_ptr(), b["flags"].data_ptr(),
                                      self.light.cuda_stream)
             self._post_lists(b, B, self.light.cuda_stream)
-            if self.post_hook is not None:
-                self.post_hook(b)
-            b["done"].record(self.light)
+            if exclusive:
+                self._pending_hook = b              # "done" is recorded behind the hook, at the next submit or flush_hook()
+            else:
+                if self.post_hook is not None:
+                    self.post_hook(b)
+                b["done"].record(self.light)
         return b
 
     def synchronize(self):
+        self.flush_hook()
         if self.prep is not None:
             self.prep.synchronize()
         self.heavy.synchronize()

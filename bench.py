@@ -217,6 +217,9 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-api-concurrent", action="store_true", help="skip the concurrent retrieve() measurement")
     ap.add_argument("--no-config4-full", action="store_true", help="skip the second timed region with the cross-encoder rerank")
+    ap.add_argument("--ce-overlap", action="store_true",
+                    help="let the cross-encoder forward share the chip with the next batches' scans (round 3's arrangement) "
+                         "instead of giving it the chip to itself")
     ap.add_argument("--ingest", action="store_true",
                     help="measure AdvancedRAGPipeline.ingest_documents instead of the search step: synthetic documents of "
                          "~512 tokens through SentenceEncoder (random-init, bge-base shape at --dim 768) + BM25SparseEncoder "
@@ -474,6 +477,7 @@ def main():
                    f"{B * args.top_k} pairs x {T} tokens per step" + (f", the queries split over the {world} ranks" if world > 1 else ""))
         if n_fly > 1:
             eng.post_hook = cross_encode
+            eng.post_hook_exclusive = not args.ce_overlap
 
     def step(i):
         if n_fly > 1:
@@ -546,6 +550,7 @@ def main():
         for T in (128, 512):
             hook, evs, pairs, ce_m = make_cross_encoder(T)
             eng.post_hook = hook
+            eng.post_hook_exclusive = not args.ce_overlap
             k_full, w_full = (10, 3) if T == 128 else (4, 2)
             for i in range(w_full):
                 step(i)
@@ -574,14 +579,17 @@ def main():
             config4_full[f"seq_len_{T}"] = {
                 "value": B * k_full / el, "unit": "queries/s", "ms_per_step": el / k_full * 1e3, "steps": k_full, "warmup": w_full,
                 "cross_encoder": ce_report(ce_m, evs, pairs, T, alone_ms),
+                "forward_placement": "shares the chip with the next batches' scans" if args.ce_overlap else
+                                     "exclusive: behind the next batch's scans, ahead of the scans after that (engine.post_hook_exclusive)",
                 "dense_scan_ms": round(ph["dense_scan"][0], 4), "sparse_scan_ms": round(ph["sparse_scan"][0], 4)}
             eng.post_hook = None
         eng.synchronize()
         config4_full["note"] = ("hybrid dense+sparse -> RRF -> cross-encoder rerank 20 -> 5: random-init MiniLM-L6-H384, fp16, every full layer "
                                 "as three hand-written HIP launches (QKV projection, attention, output projection + LayerNorm + FFN + "
                                 "LayerNorm: csrc/encoder_layer.h, attention.h), the last layer's token-0 rows and the head through "
-                                "PyTorch-ROCm; synthetic token ids; the forward runs on the finishing stream, i.e. `frac` is measured "
-                                "while the scans of the next batches share the chip — `frac_alone` is the same forward on an idle chip")
+                                "PyTorch-ROCm; synthetic token ids; the forward runs on the finishing stream with the chip to itself "
+                                "(compute-bound beside HBM-bound scans gained nothing: both slowed down), the finishing kernels of the "
+                                "batch overlap the next batch's scans; `frac_alone` is the same forward timed back to back on an idle chip")
 
     # every rank merges the same gathered lists, so every rank must hold the same fused answer for the last batch
     ranks_agree = None
@@ -982,7 +990,8 @@ def measure_latency(h, Q, SQ, args, use_sparse, world=1, rank=0, first_row=0, n_
                     ent.update({"scan_launches_per_request": scans / n_total,
                                 "mean_queries_per_scan_launch": 2 * n_total / max(scans, 1),
                                 "front_busy_frac": (st1["busy_s"] - st0["busy_s"]) / wall,
-                                "redone_unproven": st1["redone_unproven"] - st0["redone_unproven"]})
+                                "redone_unproven": st1["redone_unproven"] - st0["redone_unproven"],
+                                "rounds": st1["rounds"] - st0["rounds"]})
                 else:
                     ent["scan_launches_per_request"] = 2.0
                 api.setdefault(f"in_flight_{in_flight}", {})["coalesced" if coalesce else "uncoalesced"] = ent

@@ -86,5 +86,24 @@ def test_config4_hybrid_plus_cross_encoder_cut_at_1m_rows(gpu):
         same = torch.tensor([set(got[i]["ce_ids"][b].tolist()) == set(torch.gather(fused, 1, ref_top.indices)[b].tolist())
                              for b in range(B)], device=dev)
         assert bool(same[clear].all())
+    # the same three batches with the forward given the chip to itself (engine.post_hook_exclusive: the hook of batch i is
+    # enqueued behind the scans of batch i + 1, the last one by synchronize()): same candidates, same cut
+    recorded = []
+
+    def recording_hook(b):
+        hook(b)
+        recorded.append({k: b[k].clone() for k in ("fused_ids", "ce_ids", "ce_scores", "ce_all")})
+
+    pipe.post_hook, pipe.post_hook_exclusive = recording_hook, True
+    for i in range(3):
+        q, sq = torch.from_numpy(Q[i]).to(dev), pipe.upload_sparse(pack_sparse_queries(SQ[i], 0.2))
+        pipe.submit(q, sq)
+        assert len(recorded) == i          # batch i's hook waits for the next submit
+    pipe.synchronize()
+    assert len(recorded) == 3
+    for i in range(3):
+        assert torch.equal(recorded[i]["fused_ids"], got[i]["fused_ids"])
+        assert torch.equal(recorded[i]["ce_ids"], got[i]["ce_ids"])
+        assert torch.allclose(recorded[i]["ce_all"], got[i]["ce_all"], atol=1e-3, rtol=0)
     pipe.close()
     h.close()
