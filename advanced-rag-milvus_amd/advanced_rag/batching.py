@@ -286,7 +286,11 @@ class SearchCoalescer:
             self.stats["rounds"] += 1
             self.stats["requests"] += len(reqs)
             groups: Dict[Tuple, Dict[str, List[_Request]]] = {}
+            hybrid: Dict[Tuple, List[_Request]] = {}
             for r in reqs:
+                if r.kind == "hybrid":
+                    hybrid.setdefault(r.key, []).append(r)
+                    continue
                 if r.kind == "fuse":
                     try:
                         _deliver(r.future, self.mgr._fuse_rows_blocking(r.payload, r.key))
@@ -304,6 +308,23 @@ class SearchCoalescer:
                     continue
                 drop = float(dict(params_key).get("drop_ratio_search", 0.0)) if r.kind == "sparse" else None
                 groups.setdefault((top_k, expr), {}).setdefault((r.kind, drop), []).append(r)
+            for (top_k, expr, drop, rrf_k), rs in hybrid.items():
+                # both searches and the fusion of these requests as ONE collective round on the device (shards.round_hybrid)
+                for c0 in range(0, len(rs), 64):
+                    chunk = rs[c0:c0 + 64]
+                    try:
+                        keep = self.mgr._row_mask(expr)
+                        q = np.stack([np.asarray(r.payload[0].detach().cpu().numpy() if hasattr(r.payload[0], "detach") else r.payload[0],
+                                                 dtype=np.float32).reshape(-1) for r in chunk])
+                        res = cs.round_hybrid(q, [r.payload[1] for r in chunk], top_k, drop, rrf_k,
+                                              np.array([[r.payload[2], r.payload[3]] for r in chunk], dtype=np.float64), keep)
+                        self.stats["hybrid_launches"] += 1
+                        self.stats["max_batch_seen"] = max(self.stats["max_batch_seen"], len(chunk))
+                        self._scatter_hybrid_lists(chunk, res["fused_ids"], res["fused_scores"], res["fused_methods"], res["fused_n"],
+                                                   res["list_ids"], res["list_scores"], res["proven"])
+                    except Exception as e:
+                        for r in chunk:
+                            _fail(r.future, e)
             for (top_k, expr), by_kind in groups.items():
                 dense = next((v for (kind, _), v in by_kind.items() if kind == "dense"), [])
                 sparse_sets = [(d, v) for (kind, d), v in by_kind.items() if kind == "sparse"] or [(0.0, [])]
@@ -452,13 +473,15 @@ class SearchCoalescer:
         fi, fs = b["fused_ids"].cpu().numpy(), b["fused_scores"].cpu().numpy()
         fm, fn = b["fused_methods"].cpu().numpy(), b["fused_n"].cpu().numpy()
         ids, sc, fl = b["ids"].cpu().numpy(), b["scores"].cpu().numpy(), b["flags"].cpu().numpy()
+        self._scatter_hybrid_lists(chunk, fi, fs, fm, fn, ids, sc, fl.min(axis=0) == 1)
+
+    def _scatter_hybrid_lists(self, chunk, fi, fs, fm, fn, ids, sc, proven):
         # score of a fused row in the list its payload comes from: the dense list if the row is in it, else the sparse one
         # (HybridRetriever._assemble_fused); rows are unique within a list
         in_d = fi[:, :, None] == ids[0][:, None, :]
         in_s = fi[:, :, None] == ids[1][:, None, :]
         orig = np.where(in_d.any(axis=2), np.take_along_axis(sc[0], in_d.argmax(axis=2), axis=1),
                         np.take_along_axis(sc[1], in_s.argmax(axis=2), axis=1))
-        proven = fl.min(axis=0) == 1
         for i, r in enumerate(chunk):
             if not proven[i]:   # ties at a candidate cut: the general path redoes the searches through the host forms
                 self.stats["redone_unproven"] += 1

@@ -766,8 +766,8 @@ class MilvusIndexManager:
         if sem is None or spa is None or sem.handle is not spa.handle or 2 * int(top_k) > HR_MAX_TOPK:
             return None
         front = self._coalescer(sem)
-        if front is None or front.collective:
-            return None
+        if front is None or (front.collective and not getattr(self._main, "supports_hybrid_round", False)):
+            return None        # (the torchrun form answers in one round when its shards allow it: shards.round_hybrid)
         try:
             self._search_params(sem, semantic_params)
             sp = self._search_params(spa, sparse_params)

@@ -267,10 +267,11 @@ class CollectiveShardSet:
     shard file), row_maps (one gather) — which rank 0 calls while the other ranks sit in serve(); each is one control
     packet + its payload broadcasts + one all-reduce of a status flag, so that rank 0 hears of a failure anywhere."""
 
-    OP_STOP, OP_ROUND, OP_ADD, OP_FLUSH, OP_SAVE, OP_ROWMAPS = 0, 1, 2, 3, 4, 5
+    OP_STOP, OP_ROUND, OP_ADD, OP_FLUSH, OP_SAVE, OP_ROWMAPS, OP_HYBRID = 0, 1, 2, 3, 4, 5, 6
     HEADER = 16                     # int64 words
     PACKET_BYTES = 1 << 20          # header + queries of one round (128 x (768-d dense + 100-term sparse) = 0.5 MB)
     MAX_MASKS = 8
+    hybrid_on_device = True         # False: retrieve() takes the two-searches-then-fuse rounds through the host forms (round 3)
 
     def __init__(self, local: ShardSet, first_row: int, dist, group=None, device=None, local_ids: bool = False):
         import threading
@@ -297,6 +298,8 @@ class CollectiveShardSet:
         self._next_mask_id = 1
         self.n_collectives = 0      # broadcasts + gathers issued (tests count them)
         self._side = None           # one worker thread: the dense search of a round that also carries sparse queries
+        self._hyb_engines = {}      # (top_k, rrf_k) -> engine.HybridSearchEngine over the group (hybrid rounds on the device)
+        self._dev_masks = {}        # mask id -> this rank's packed row mask in HBM
 
     # shape, as ShardSet
     n_shards = property(lambda self: self.world)
@@ -389,6 +392,7 @@ class CollectiveShardSet:
                 self._n_sparse += nrows
             self._masks.clear()          # row slices of cached filters are stale on every rank
             self._mask_ids.clear()
+            self._dev_masks.clear()
             sparse_err = None
             if hi > lo:
                 piece_csr = None if csr is None else (csr[0][lo:hi + 1], csr[1], csr[2])
@@ -479,17 +483,7 @@ class CollectiveShardSet:
             if idx.shape != val.shape:
                 raise ValueError("sparse query indices/values length mismatch")
             parts += [ptr.view(np.uint8), idx.view(np.uint8), val.view(np.uint8)]
-        mask_id, mask_new, mask_bytes = 0, 0, None
-        if keep is not None:
-            ent = self._mask_ids.get(id(keep))
-            if ent is None or ent[0] not in self._masks:
-                mask_id, mask_new = self._next_mask_id, 1
-                self._next_mask_id += 1
-                self._mask_ids = {key: v for key, v in self._mask_ids.items() if v[0] in self._masks}
-                self._mask_ids[id(keep)] = (mask_id, keep)
-                mask_bytes = np.packbits(np.asarray(keep, dtype=bool), bitorder="little")
-            else:
-                mask_id = ent[0]
+        mask_id, mask_new, mask_bytes = self._mask_for(keep)
         hdr = np.zeros(self.HEADER, dtype=np.int64)
         hdr[:10] = [self.OP_ROUND, Bd, Bs, k, dim, nnz, int(np.array([drop], dtype=np.float64).view(np.int64)[0]), mask_id,
                     mask_new, 0 if mask_bytes is None else mask_bytes.size]
@@ -580,6 +574,8 @@ class CollectiveShardSet:
         hdr = pkt[: self.HEADER * 8].view(np.int64)
         if int(hdr[0]) == self.OP_STOP:
             return False
+        if int(hdr[0]) == self.OP_HYBRID:
+            return self._hybrid_round(pkt, hdr, mask_bytes)
         if int(hdr[0]) != self.OP_ROUND:     # a worker picked up a control operation of rank 0
             op = int(hdr[0])
             if op == self.OP_ADD:
@@ -630,6 +626,108 @@ class CollectiveShardSet:
             out.append(merge_lists(ids, scs, k))
             o += B * k
         return out
+
+    # ------------------------------------------------------------------ hybrid rounds on the device
+    @property
+    def supports_hybrid_round(self) -> bool:
+        """The device form of a hybrid round needs real shards whose handles return GLOBAL rows (pre-built contiguous
+        shards: the engine merges the ranks' lists by the ids the scans wrote) and the sparse modality."""
+        h = self.local.first
+        return (self.hybrid_on_device and not self.local_ids and getattr(h, "_h", None) is not None
+                and getattr(h, "sparse_dim", 0) > 0)
+
+    def round_hybrid(self, dense_q: np.ndarray, sparse_queries, top_k: int, drop_ratio: float, rrf_k: int,
+                     weights: np.ndarray, keep: Optional[np.ndarray] = None):
+        """rank 0: the dense search (2 x top_k), the sparse search (2 x top_k) and their rank fusion for B requests as ONE
+        collective round on the device: the packet (queries, CSR, per-request weights) is broadcast, every rank runs
+        hr_search_hybrid_dev on its shard with pointers INTO the packet, the per-rank lists travel in the engine's one
+        all-gather and every rank merges + fuses them in one launch (engine.HybridSearchEngine with the process group: the
+        path bench.py times) — under nccl nothing but the 128-byte header and rank 0's answer crosses the host.
+        -> dict of numpy arrays: fused_ids / fused_scores / fused_methods [B, top_k], fused_n [B], list_ids /
+        list_scores [2, B, k'], proven [B] (False: some rank could not prove a list — the caller redoes that request
+        through the host forms)."""
+        from .engine import pack_sparse_queries
+        dense_q = np.ascontiguousarray(np.atleast_2d(dense_q), dtype=np.float32)
+        B, dim = dense_q.shape
+        h = self.local.first
+        if dim != h.dim:
+            raise ValueError(f"query dim {dim} != shard dim {h.dim}")
+        ptr, idx, val, max_nnz = pack_sparse_queries(list(sparse_queries), float(drop_ratio), h.sparse_dim)
+        if len(ptr) != B + 1 or not idx.size:
+            raise ValueError("a hybrid round needs one non-empty sparse query per dense query")
+        w = np.zeros((B, 3), dtype=np.float64)
+        w[:, :2] = np.asarray(weights, dtype=np.float64).reshape(B, 2)
+        with self._lock:
+            mask_id, mask_new, mask_bytes = self._mask_for(keep)
+            # 8-byte items first: every view of the packet is aligned for its type
+            blob = np.concatenate([ptr.astype(np.int64).view(np.uint8), w.view(np.uint8).reshape(-1), dense_q.view(np.uint8).reshape(-1),
+                                   idx.astype(np.int32).view(np.uint8), val.astype(np.float32).view(np.uint8)])
+            hdr = np.zeros(self.HEADER, dtype=np.int64)
+            hdr[:11] = [self.OP_HYBRID, B, int(top_k), dim, int(idx.size), int(rrf_k), 0, mask_id, mask_new,
+                        0 if mask_bytes is None else mask_bytes.size, int(max_nnz)]
+            hdr[self.HEADER - 1] = blob.size
+            body = np.concatenate([hdr.view(np.uint8), blob])
+            if body.size > self.PACKET_BYTES:
+                raise ValueError(f"a hybrid round of {B} requests needs {body.size} bytes; the packet holds {self.PACKET_BYTES}")
+            return self._round(body, mask_bytes)
+
+    def _hybrid_round(self, pkt: np.ndarray, hdr, mask_bytes):
+        """Every rank's part of a hybrid round (collective: the engine's all-gather is inside)."""
+        from .engine import EngineConfig, HybridSearchEngine
+        t = self.torch
+        B, top_k, dim, nnz, rrf_k = (int(x) for x in hdr[1:6])
+        max_nnz = int(hdr[10])
+        keep_local = self._mask_slice(hdr, mask_bytes)
+        dev = t.device("cuda", self.local.first.device)
+        eng = self._hyb_engines.get((top_k, rrf_k))
+        if eng is None:
+            if len(self._hyb_engines) >= 8:
+                self._hyb_engines.clear()
+            eng = self._hyb_engines[(top_k, rrf_k)] = HybridSearchEngine(
+                self.local.first, EngineConfig(top_k=top_k, rrf_k=rrf_k, enable_reranking=False), process_group=self.group, device=str(dev))
+        # the operands are views of the packet where it lives on the device (nccl), uploads of its host copy otherwise
+        src = self._packet if self._packet.is_cuda else t.from_numpy(pkt[: self.HEADER * 8 + int(hdr[self.HEADER - 1])]).to(dev)
+        o = self.HEADER * 8
+
+        def view(n_bytes, dtype):
+            nonlocal o
+            v = src[o: o + n_bytes].view(dtype)
+            o += n_bytes
+            return v
+        ptr = view((B + 1) * 8, t.int64)
+        wq = view(B * 24, t.float64).view(B, 3)
+        q = view(B * dim * 4, t.float32).view(B, dim)
+        idx = view(nnz * 4, t.int32)
+        val = view(nnz * 4, t.float32)
+        mask = None
+        if keep_local is not None:
+            mid = int(hdr[7])
+            mask = self._dev_masks.get(mid)
+            if mask is None:
+                if len(self._dev_masks) >= self.MAX_MASKS:
+                    self._dev_masks.pop(next(iter(self._dev_masks)))
+                mask = self._dev_masks[mid] = t.from_numpy(np.packbits(keep_local, bitorder="little")).to(dev)
+        with t.cuda.device(dev):
+            b = eng.search(q, (ptr, idx, val, max_nnz), rowmask=mask, weights=wq)
+            t.cuda.current_stream(dev).synchronize()      # the packet may be rewritten by the next round
+        if self.rank != 0:
+            return True
+        out = {k: b[k].cpu().numpy() for k in ("fused_ids", "fused_scores", "fused_methods", "fused_n", "list_ids", "list_scores")}
+        out["proven"] = b["agg_flags"].cpu().numpy().min(axis=0) == 1
+        return out
+
+    def _mask_for(self, keep):
+        """rank 0: (mask id, 1 if the mask must travel with this round, its packed bytes or None) of a filter array."""
+        if keep is None:
+            return 0, 0, None
+        ent = self._mask_ids.get(id(keep))
+        if ent is not None and ent[0] in self._masks:
+            return ent[0], 0, None
+        mask_id = self._next_mask_id
+        self._next_mask_id += 1
+        self._mask_ids = {key: v for key, v in self._mask_ids.items() if v[0] in self._masks}
+        self._mask_ids[id(keep)] = (mask_id, keep)
+        return mask_id, 1, np.packbits(np.asarray(keep, dtype=bool), bitorder="little")
 
     # ------------------------------------------------------------------ rank 0
     def round(self, dense_q: Optional[np.ndarray], sparse_queries, k: int, drop_ratio: float = 0.0, keep: Optional[np.ndarray] = None):
