@@ -87,21 +87,22 @@ class AdaptiveChunker:
         target = self._target_size(diagnostics)
         overlap = int(target * self.overlap_ratio)
         sentences = [s.strip() for s in _SENT.split(text) if s.strip()]
-        windows, cur, cur_tok, pos, start = [], [], 0, 0, 0
+        windows, cur, cur_n, cur_tok, pos, start = [], [], [], 0, 0, 0   # cur_n: token counts of the sentences in cur
         for s in sentences:
             n = len(tokenize(s))
             if cur and cur_tok + n > target:
                 windows.append((" ".join(cur), start, pos))
-                keep, kept = [], 0
-                for prev in reversed(cur):
-                    pn = len(tokenize(prev))
+                keep, keep_n, kept = [], [], 0
+                for prev, pn in zip(reversed(cur), reversed(cur_n)):
                     if kept + pn > overlap:
                         break
                     keep.insert(0, prev)
+                    keep_n.insert(0, pn)
                     kept += pn
-                cur, cur_tok = keep, kept
+                cur, cur_n, cur_tok = keep, keep_n, kept
                 start = pos - sum(len(x) + 1 for x in keep)
             cur.append(s)
+            cur_n.append(n)
             cur_tok += n
             pos += len(s) + 1
         if cur:

@@ -23,7 +23,7 @@ import math
 import re
 import zlib
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -60,17 +60,30 @@ class HashTokenizer:
     """Dependency-free stand-in for WordPiece: lower-cased words/punctuation hashed
     (crc32) into the vocabulary.  Real vocabularies are not available offline."""
 
+    _MEMO_MAX = 1 << 20
+
     def __init__(self, vocab_size: int = 30522, max_len: int = 512):
         self.vocab_size, self.max_len = vocab_size, max_len
+        self._memo: Dict[str, int] = {}      # token -> id: a corpus repeats its vocabulary, the hash is paid once per token
 
-    def _ids(self, text: str) -> List[int]:
-        return [1000 + zlib.crc32(t.encode("utf-8")) % (self.vocab_size - 1000) for t in _WORD.findall(text.lower())]
+    def _id(self, t: str) -> int:
+        i = 1000 + zlib.crc32(t.encode("utf-8")) % (self.vocab_size - 1000)
+        if len(self._memo) < self._MEMO_MAX:
+            self._memo[t] = i
+        return i
+
+    def _ids(self, text: str, limit: Optional[int] = None) -> List[int]:
+        memo, slow = self._memo, self._id
+        toks = _WORD.findall(text.lower())
+        if limit is not None:
+            toks = toks[:limit]              # what lies beyond max_len is never encoded
+        return [memo[t] if t in memo else slow(t) for t in toks]
 
     def encode(self, text: str, pair: Optional[str] = None) -> Tuple[List[int], List[int]]:
-        a = self._ids(text)
         if pair is None:
-            ids = [CLS] + a[: self.max_len - 2] + [SEP]
+            ids = [CLS] + self._ids(text, self.max_len - 2) + [SEP]
             return ids, [0] * len(ids)
+        a = self._ids(text)
         b = self._ids(pair)
         room = self.max_len - 3
         a = a[: max(1, min(len(a), room // 2))]
@@ -82,11 +95,13 @@ class HashTokenizer:
         enc = [self.encode(t, None if pairs is None else pairs[i]) for i, t in enumerate(texts)]
         width = max(len(i) for i, _ in enc)
         width = -(-width // 8) * 8  # friendlier GEMM shapes
-        ids = torch.full((len(enc), width), PAD, dtype=torch.long)
-        types = torch.zeros((len(enc), width), dtype=torch.long)
+        ids_h = np.full((len(enc), width), PAD, dtype=np.int64)      # one host array, one conversion (was a tensor per row)
+        types_h = np.zeros((len(enc), width), dtype=np.int64)
         for r, (i, t) in enumerate(enc):
-            ids[r, : len(i)] = torch.tensor(i)
-            types[r, : len(t)] = torch.tensor(t)
+            ids_h[r, : len(i)] = i
+            if pairs is not None:
+                types_h[r, : len(t)] = t
+        ids, types = torch.from_numpy(ids_h), torch.from_numpy(types_h)
         return ids.to(device), types.to(device), (ids != PAD).to(device)
 
 
