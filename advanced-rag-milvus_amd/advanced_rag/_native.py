@@ -69,6 +69,8 @@ _SIGNATURES = {
                                           _c.c_float, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "hr_filter_eval_dev": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p,
                                       _c.c_void_p, _c.c_void_p]),
+    "hr_bm25_encode_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
+                                      _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "hr_fuse_rrf": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int,
                                _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_void_p,
                                _c.c_void_p, _c.c_void_p]),
@@ -444,6 +446,17 @@ def filter_eval_dev(terms: Sequence["FilterTerm"], n_rows: int, d_deleted: int, 
     arr = (FilterTerm * max(len(terms), 1))(*terms)
     rc = L.hr_filter_eval_dev(ctypes.byref(arr), len(terms), n_rows, _vp(d_deleted) if d_deleted else None, _vp(d_mask),
                               _vp(d_undecided), _vp(d_counts), _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def bm25_encode_dev(d_text: int, d_off: int, n_docs: int, sparse_dim: int, k1: float, b: float, avgdl: float, cap: int,
+                    d_idx: int, d_val: int, d_nnz: int, d_flags: int, stream: int = 0):
+    """hr_bm25_encode_dev: BM25 document payloads of a batch on the device (include/hbmrag.h)."""
+    L = load_library()
+    rc = L.hr_bm25_encode_dev(_vp(d_text) if d_text else None, _vp(d_off), n_docs, sparse_dim, float(k1), float(b), float(avgdl), cap,
+                              _vp(d_idx) if d_idx else None, _vp(d_val) if d_val else None, _vp(d_nnz), _vp(d_flags),
+                              _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
 

@@ -116,6 +116,55 @@ class BM25SparseEncoder:
         order = np.argsort(idx, kind="stable")
         return {"indices": idx[order].tolist(), "values": w[order].astype(np.float64).tolist()}
 
+    def encode_documents_csr(self, texts, device=None):
+        """The payloads of a BATCH of documents as one CSR (indptr int64 [n + 1], indices int32, values float32), rows =
+        encode_document(text) bit for bit.  With `device` (a CUDA device) the batch is tokenised, hashed, counted and
+        weighed by ONE launch of hr_bm25_encode_dev (csrc/text.h); documents it flags (non-ASCII bytes, longer than 64 KiB)
+        are encoded here.  Without a device — or when the vocabulary is wider than the kernel's histogram — every
+        document is."""
+        texts = list(texts)
+        n = len(texts)
+        rows: List = [None] * n
+        todo = range(n)
+        if device is not None and n and self.sparse_dim <= 65536:
+            import torch
+            from . import _native
+            raw = [t.encode("utf-8") for t in texts]
+            off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum([len(r) for r in raw], out=off[1:])
+            cap = int(min(self.sparse_dim, max(len(r) for r in raw) // 2 + 1))
+            dev = torch.device(device)
+            d_text = torch.frombuffer(bytearray(b"".join(raw) or b"\0"), dtype=torch.uint8).to(dev)
+            d_off = torch.from_numpy(off).to(dev)
+            d_idx = torch.empty((n, cap), dtype=torch.int32, device=dev)
+            d_val = torch.empty((n, cap), dtype=torch.float32, device=dev)
+            d_nnz = torch.empty(n, dtype=torch.int32, device=dev)
+            d_flags = torch.empty(n, dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _native.bm25_encode_dev(d_text.data_ptr(), d_off.data_ptr(), n, self.sparse_dim, self.k1, self.b, self.avgdl, cap,
+                                        d_idx.data_ptr(), d_val.data_ptr(), d_nnz.data_ptr(), d_flags.data_ptr(),
+                                        torch.cuda.current_stream(dev).cuda_stream)
+                nnz = d_nnz.cpu().numpy()
+                flags = d_flags.cpu().numpy()
+                keep = torch.arange(cap, device=dev)[None, :] < d_nnz[:, None]
+                idx_all, val_all = d_idx[keep].cpu().numpy(), d_val[keep].cpu().numpy()   # row-major: document order
+            ptr = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(nnz, out=ptr[1:])
+            todo = np.nonzero(flags)[0].tolist()
+            if not todo:
+                return ptr, idx_all, val_all
+            for i in range(n):
+                if not flags[i]:
+                    rows[i] = (idx_all[ptr[i]:ptr[i + 1]], val_all[ptr[i]:ptr[i + 1]])
+        for i in todo:
+            p = self.encode_document(texts[i])
+            rows[i] = (np.asarray(p["indices"], dtype=np.int32), np.asarray(p["values"], dtype=np.float32))
+        ptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(r[0]) for r in rows], out=ptr[1:])
+        idx = np.concatenate([r[0] for r in rows]).astype(np.int32) if n else np.zeros(0, np.int32)
+        val = np.concatenate([r[1] for r in rows]).astype(np.float32) if n else np.zeros(0, np.float32)
+        return ptr, idx, val
+
     def encode_query(self, text: str) -> Dict[str, List]:
         out: Dict[int, float] = {}
         for s in self._slots(text):

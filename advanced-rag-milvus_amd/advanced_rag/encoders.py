@@ -433,6 +433,14 @@ class SentenceEncoder(_Base):
             raise RuntimeError("no sparse encoder configured (pass sparse_encoder=BM25SparseEncoder(...))")
         return self.sparse_encoder.encode_document(text)
 
+    def encode_sparse_csr(self, texts: Sequence[str]):
+        """Batch form of encode_sparse for the ingest path: (indptr int64, indices int32, values float32) of all the texts —
+        one launch on the encoder's GPU (hr_bm25_encode_dev) instead of a Python call per chunk."""
+        if self.sparse_encoder is None:
+            raise RuntimeError("no sparse encoder configured (pass sparse_encoder=BM25SparseEncoder(...))")
+        dev = torch.device(self.device)
+        return self.sparse_encoder.encode_documents_csr(texts, device=dev if dev.type == "cuda" else None)
+
     def encode_sparse_query(self, text: str):
         if self.sparse_encoder is None:
             raise RuntimeError("no sparse encoder configured")

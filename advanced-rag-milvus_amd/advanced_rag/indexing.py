@@ -351,6 +351,15 @@ class MilvusIndexManager:
             dense_vecs = None
         else:
             dense_vecs = await self._generate_semantic_embeddings_batch(texts)
+        # sparse payloads of the whole call from ONE hook call when the generator offers the batch form (SentenceEncoder:
+        # hr_bm25_encode_dev on its GPU; the reference calls encode_sparse once per chunk, indexing.py:379-404); a batch the
+        # hook or the checks below refuse goes chunk by chunk, where a bad payload costs only its own row
+        sparse_batch = None
+        if use_sparse and chunks and gen is not None and hasattr(gen, "encode_sparse_csr"):
+            try:
+                sparse_batch = self._checked_sparse_csr(await self._run_encoder(gen.encode_sparse_csr, texts), len(chunks))
+            except Exception as e:
+                logger.warning("batched sparse payloads failed (%s); encoding chunk by chunk", e)
         rows_dense, rows_domain, sp_ptr, sp_idx, sp_val, kept, kept_idx = [], [], [0], [], [], [], []
         n_sparse_ok = 0
         for i, chunk in enumerate(chunks):
@@ -361,7 +370,11 @@ class MilvusIndexManager:
                     if dense.shape[0] != self.semantic_dim:
                         raise ValueError(f"semantic embedding has dim {dense.shape[0]}, expected {self.semantic_dim}")
                 sp = None
-                if use_sparse:
+                if sparse_batch is not None:
+                    bp, bi, bv = sparse_batch
+                    sp = (bi[bp[i]:bp[i + 1]], bv[bp[i]:bp[i + 1]])
+                    n_sparse_ok += 1
+                elif use_sparse:
                     try:
                         sp = self._clean_sparse_payload(await self._generate_sparse_embedding(chunk.text, role="document"))
                         n_sparse_ok += 1
@@ -604,6 +617,23 @@ class MilvusIndexManager:
             raise ValueError("sparse indices/values length mismatch")
         order = np.argsort(idx, kind="stable")
         return idx[order], val[order]
+
+    def _checked_sparse_csr(self, csr, n: int):
+        """A batch hook's CSR as (indptr int64, indices int32, values float32) if it is what the shard accepts as it stands —
+        n rows, indices inside [0, sparse_dim) and strictly ascending within a row, finite values, rows of at most 60 000
+        entries — else None (the per-chunk path then cleans or rejects payload by payload)."""
+        ptr, idx, val = (np.asarray(csr[0], dtype=np.int64), np.asarray(csr[1], dtype=np.int32), np.asarray(csr[2], dtype=np.float32))
+        if ptr.shape != (n + 1,) or ptr[0] != 0 or ptr[-1] != idx.shape[0] or idx.shape != val.shape or (np.diff(ptr) < 0).any():
+            return None
+        if idx.size:
+            if idx.min() < 0 or idx.max() >= self.sparse_dim or not np.isfinite(val).all() or np.diff(ptr).max() > 60000:
+                return None
+            asc = np.ones(idx.size, dtype=bool)
+            asc[1:] = idx[1:] > idx[:-1]
+            asc[ptr[:-1][ptr[:-1] < idx.size]] = True          # the first entry of a row has no predecessor in its row
+            if not asc.all():
+                return None
+        return ptr, idx, val
 
     def _clean_sparse_payload(self, emb):
         """A DOCUMENT's sparse payload, made acceptable to the shard or rejected here, chunk by chunk — a whole batch

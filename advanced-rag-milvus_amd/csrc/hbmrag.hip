@@ -29,6 +29,7 @@
 #include "filter.h"
 #include "finish.h"
 #include "fuse.h"
+#include "text.h"
 #include "select.h"
 #include "sparse.h"
 
@@ -1798,6 +1799,30 @@ int hr_filter_eval_dev(const hr_filter_term* terms, int n_terms, int64_t n_rows,
     hipLaunchKernelGGL(filter_eval_kernel, dim3(blocks), dim3(256), 0, s, a);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(nullptr, HR_EHIP, "filter_eval_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
+int hr_bm25_encode_dev(const uint8_t* d_text, const int64_t* d_off, int n_docs, int sparse_dim, double k1, double b,
+                       double avgdl, int cap, int32_t* d_idx, float* d_val, int32_t* d_nnz, int32_t* d_flags, void* stream) {
+    if (n_docs < 0 || !d_off || !d_nnz || !d_flags || (n_docs > 0 && (!d_text || !d_idx || !d_val)))
+        return fail(nullptr, HR_EINVAL, "bad bm25 arguments");
+    if (sparse_dim < 1 || sparse_dim > kBm25MaxDim) return fail(nullptr, HR_ELIMIT, "sparse_dim must be 1..%d for the device encoder", kBm25MaxDim);
+    if (cap < 1 || !(avgdl > 0.0) || !(k1 >= 0.0) || !(b >= 0.0 && b <= 1.0)) return fail(nullptr, HR_EINVAL, "bad bm25 parameters");
+    if (n_docs == 0) return HR_OK;
+    Bm25Args a{};
+    a.text = d_text; a.off = d_off; a.n_docs = n_docs; a.sparse_dim = sparse_dim; a.cap = cap;
+    a.k1 = k1; a.b = b; a.avgdl = avgdl;
+    a.idx = d_idx; a.val = d_val; a.nnz = d_nnz; a.flags = d_flags;
+    const size_t lds = (size_t)((sparse_dim + 1) / 2) * 4;
+    static bool attr_set = false;  // benign race: the attribute is idempotent
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)bm25_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (kBm25MaxDim / 2) * 4);
+        if (e != hipSuccess) return fail(nullptr, HR_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(bm25_encode_kernel, dim3((unsigned)n_docs), dim3(kBm25Threads), lds, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "bm25_encode_kernel: %s", hipGetErrorString(e));
     return HR_OK;
 }
 

@@ -309,6 +309,18 @@ typedef struct hr_filter_term {
 HR_API int hr_filter_eval_dev(const hr_filter_term* terms, int n_terms, int64_t n_rows, const uint8_t* d_deleted,
                        uint8_t* d_mask, uint8_t* d_undecided, int32_t* d_counts, void* stream);
 
+/* ---- BM25 document payloads (ingest) ----------------------------------------------------------------------------
+ * The `encode_sparse` hook of the ingest path (reference indexing.py:629-654, called per chunk from index_chunks
+ * :379-404) for the BM25 encoder of this build (advanced_rag/bm25.py), a batch at a time on the device: d_text = the
+ * documents' UTF-8 bytes back to back, d_off[n_docs + 1] their byte offsets.  Per document: lower-cased `\b\w+\b` tokens
+ * (ASCII classes), slot = crc32(token) mod sparse_dim, weight = (float)(tf (k1 + 1) / (tf + k1 (1 - b + b dl / avgdl))) in
+ * double — bit for bit what BM25SparseEncoder.encode_document returns.  Out: d_idx / d_val [n_docs][cap] (slots ascending),
+ * d_nnz[n_docs], d_flags[n_docs]: 0 = encoded, 1 = the document holds a byte >= 0x80 (Unicode case mapping and
+ * categories are the host's), 2 = longer than 65 535 bytes or more than `cap` distinct slots — flagged documents have
+ * nnz = 0 and are encoded by the caller on the host.  sparse_dim <= 65 536.  Asynchronous on `stream`. */
+HR_API int hr_bm25_encode_dev(const uint8_t* d_text, const int64_t* d_off, int n_docs, int sparse_dim, double k1, double b,
+                       double avgdl, int cap, int32_t* d_idx, float* d_val, int32_t* d_nnz, int32_t* d_flags, void* stream);
+
 /* ---- encoder / cross-encoder forward: fused elementwise pieces -----------------
  * The GEMMs and the attention of the PyTorch-ROCm encoder forwards stay with
  * hipBLASLt / SDPA; this is the residual add + LayerNorm every post-LN BERT

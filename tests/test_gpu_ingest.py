@@ -251,3 +251,50 @@ def test_device_to_device_ingest_equals_host_ingest(gpu):
     assert all(np.array_equal(a, b) for a, b in zip(md._main.first.search_sparse(sq, 20, 0.2), mh._main.first.search_sparse(sq, 20, 0.2)))
     for p in mgrs.values():
         asyncio.run(p.close())
+
+
+def test_bm25_payloads_on_the_device_equal_the_host_encoder(gpu):
+    """hr_bm25_encode_dev (csrc/text.h) against BM25SparseEncoder.encode_document — the host restatement of the same
+    arithmetic and the fallback of the batch form — bit for bit: indices, float32 weight bits, row lengths.  Mixed case,
+    digits, underscores, punctuation runs, tokens at both ends of a document, an empty document, a single very long
+    token, a document of one byte; documents the kernel must hand back (a non-ASCII byte; longer than 65 535 bytes) come
+    out identical through the fallback; vocabularies of 257 / 10 000 / 65 536 slots on the device and 70 000 on the host."""
+    from advanced_rag import BM25SparseEncoder
+    rng = np.random.default_rng(12)
+    words = [f"w{i}" for i in range(4000)] + ["Alpha", "BETA", "gamma_9", "_x_", "42", "a", "Z"]
+    seps = [" ", ", ", ". ", "\n", " - ", "!!", "\t", "(", ")", "'s "]
+
+    def doc(n):
+        return "".join(str(rng.choice(words)) + str(rng.choice(seps)) for _ in range(n))
+
+    texts = [doc(int(n)) for n in rng.integers(1, 700, size=200)]
+    texts += ["", "x", "x" * 5000, "...---...", "end", "Start middle END", "under_score and 123 and CamelCase",
+              "naïve café déjà vu", "plain then ünïcode", doc(20000)]
+    assert len(texts[-1].encode()) > 65535
+    for dim in (257, 10000, 65536, 70000):
+        enc = BM25SparseEncoder(sparse_dim=dim).fit(texts[:150])
+        ptr, idx, val = enc.encode_documents_csr(texts, device="cuda:0")
+        assert ptr.shape == (len(texts) + 1,) and ptr[-1] == idx.shape[0] == val.shape[0]
+        for i, t in enumerate(texts):
+            want = enc.encode_document(t)
+            assert idx[ptr[i]:ptr[i + 1]].tolist() == want["indices"], (dim, i, t[:40])
+            assert np.array_equal(_bits(val[ptr[i]:ptr[i + 1]]), _bits(np.asarray(want["values"], np.float32))), (dim, i)
+    # the flags themselves, straight from the entry point
+    enc = BM25SparseEncoder(sparse_dim=1000).fit(texts[:50])
+    raw = [t.encode() for t in ("ascii only", "café", "y" * 70000, "a b c d e f g h")]
+    off = np.zeros(len(raw) + 1, np.int64)
+    np.cumsum([len(r) for r in raw], out=off[1:])
+    d_text = torch.frombuffer(bytearray(b"".join(raw)), dtype=torch.uint8).cuda()
+    d_off = torch.from_numpy(off).cuda()
+    cap = 4
+    d_idx = torch.empty((4, cap), dtype=torch.int32, device="cuda")
+    d_val = torch.empty((4, cap), dtype=torch.float32, device="cuda")
+    d_nnz = torch.empty(4, dtype=torch.int32, device="cuda")
+    d_fl = torch.empty(4, dtype=torch.int32, device="cuda")
+    nat.bm25_encode_dev(d_text.data_ptr(), d_off.data_ptr(), 4, 1000, enc.k1, enc.b, enc.avgdl, cap, d_idx.data_ptr(),
+                        d_val.data_ptr(), d_nnz.data_ptr(), d_fl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert d_fl.tolist() == [0, 1, 2, 2] and d_nnz.tolist() == [2, 0, 0, 0]    # the last one has 8 slots, cap is 4
+    with pytest.raises(nat.HbmRagError):
+        nat.bm25_encode_dev(d_text.data_ptr(), d_off.data_ptr(), 4, 70000, enc.k1, enc.b, enc.avgdl, cap, d_idx.data_ptr(),
+                            d_val.data_ptr(), d_nnz.data_ptr(), d_fl.data_ptr(), 0)
