@@ -71,6 +71,8 @@ _SIGNATURES = {
                                       _c.c_void_p, _c.c_void_p]),
     "hr_bm25_encode_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_double, _c.c_double, _c.c_double, _c.c_int,
                                       _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "hr_hash_tokenize_dev": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p,
+                                        _c.c_void_p]),
     "hr_fuse_rrf": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_int,
                                _c.c_double, _c.c_double, _c.c_double, _c.c_int, _c.c_void_p, _c.c_void_p,
                                _c.c_void_p, _c.c_void_p]),
@@ -457,6 +459,16 @@ def bm25_encode_dev(d_text: int, d_off: int, n_docs: int, sparse_dim: int, k1: f
     rc = L.hr_bm25_encode_dev(_vp(d_text) if d_text else None, _vp(d_off), n_docs, sparse_dim, float(k1), float(b), float(avgdl), cap,
                               _vp(d_idx) if d_idx else None, _vp(d_val) if d_val else None, _vp(d_nnz), _vp(d_flags),
                               _vp(stream) if stream else None)
+    if rc != 0:
+        _raise_global(L, rc)
+
+
+def hash_tokenize_dev(d_text: int, d_off: int, n: int, max_len: int, vocab: int, d_ids: int, d_lens: int, d_flags: int,
+                      stream: int = 0):
+    """hr_hash_tokenize_dev: the hash tokenizer of the encoder hooks for a batch of texts (include/hbmrag.h)."""
+    L = load_library()
+    rc = L.hr_hash_tokenize_dev(_vp(d_text) if d_text else None, _vp(d_off), n, max_len, vocab, _vp(d_ids) if d_ids else None,
+                                _vp(d_lens), _vp(d_flags), _vp(stream) if stream else None)
     if rc != 0:
         _raise_global(L, rc)
 

@@ -91,7 +91,34 @@ class HashTokenizer:
         ids = [CLS] + a + [SEP] + b + [SEP]
         return ids, [0] * (len(a) + 2) + [1] * (len(b) + 1)
 
+    def _batch_on_device(self, texts: Sequence[str], dev):
+        """Single texts tokenised by ONE launch on the GPU (hr_hash_tokenize_dev, csrc/text.h): the bytes go up once, the ids
+        never come down.  None when a text is not ASCII (Unicode case mapping / categories are Python's): the host path."""
+        from . import _native
+        raw = [t.encode("utf-8") for t in texts]
+        n = len(raw)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in raw], out=off[1:])
+        d_text = torch.frombuffer(bytearray(b"".join(raw) or b"\0"), dtype=torch.uint8).to(dev)
+        d_off = torch.from_numpy(off).to(dev)
+        ids = torch.empty((n, self.max_len), dtype=torch.long, device=dev)
+        lens = torch.empty(n, dtype=torch.int32, device=dev)
+        flags = torch.empty(n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _native.hash_tokenize_dev(d_text.data_ptr(), d_off.data_ptr(), n, self.max_len, self.vocab_size, ids.data_ptr(),
+                                      lens.data_ptr(), flags.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+            stat = torch.stack([lens.max(), flags.max()]).cpu()
+        if int(stat[1]):
+            return None
+        width = -(-int(stat[0]) // 8) * 8
+        ids = ids[:, :width].contiguous() if width <= self.max_len else torch.nn.functional.pad(ids, (0, width - self.max_len))
+        return ids, torch.zeros_like(ids), ids != PAD
+
     def batch(self, texts: Sequence[str], pairs: Optional[Sequence[str]] = None, device="cpu"):
+        if pairs is None and len(texts) and torch.device(device).type == "cuda":
+            on_dev = self._batch_on_device(texts, torch.device(device))
+            if on_dev is not None:
+                return on_dev
         enc = [self.encode(t, None if pairs is None else pairs[i]) for i, t in enumerate(texts)]
         width = max(len(i) for i, _ in enc)
         width = -(-width // 8) * 8  # friendlier GEMM shapes

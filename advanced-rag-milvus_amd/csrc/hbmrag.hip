@@ -1826,6 +1826,20 @@ int hr_bm25_encode_dev(const uint8_t* d_text, const int64_t* d_off, int n_docs, 
     return HR_OK;
 }
 
+int hr_hash_tokenize_dev(const uint8_t* d_text, const int64_t* d_off, int n, int max_len, int vocab, int64_t* d_ids,
+                         int32_t* d_lens, int32_t* d_flags, void* stream) {
+    if (n < 0 || !d_off || !d_lens || !d_flags || (n > 0 && (!d_text || !d_ids))) return fail(nullptr, HR_EINVAL, "bad tokenizer arguments");
+    if (max_len < 3 || vocab <= 1000) return fail(nullptr, HR_EINVAL, "max_len must be >= 3 and the vocabulary larger than 1000");
+    if (n == 0) return HR_OK;
+    TokArgs a{};
+    a.text = d_text; a.off = d_off; a.n = n; a.max_len = max_len; a.vocab = vocab;
+    a.ids = d_ids; a.lens = d_lens; a.flags = d_flags;
+    hipLaunchKernelGGL(hash_tokenize_kernel, dim3((unsigned)n), dim3(kTokThreads), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(nullptr, HR_EHIP, "hash_tokenize_kernel: %s", hipGetErrorString(e));
+    return HR_OK;
+}
+
 int hr_stream_create(int device, int priority, const uint32_t* cu_mask, int n_words, void** out_stream) {
     if (!out_stream || n_words < 0 || (n_words > 0 && !cu_mask)) return fail(nullptr, HR_EINVAL, "bad stream arguments");
     *out_stream = nullptr;

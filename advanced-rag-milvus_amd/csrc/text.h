@@ -117,4 +117,93 @@ __global__ __launch_bounds__(kBm25Threads) void bm25_encode_kernel(Bm25Args a) {
     if (tid == 0) { a.nnz[d] = (int32_t)total; a.flags[d] = 0; }
 }
 
+// ---- the hash tokenizer of the encoder hooks on the device ------------------------------------------------------
+// advanced_rag/encoders.py::HashTokenizer (the offline stand-in for WordPiece in front of the sentence encoder: reference
+// hook embedding_generator.encode_semantic, indexing.py:610-620, batch form :580-587): tokens of the lower-cased text =
+// `\w+|[^\w\s]` (a word run, or ONE character that is neither word nor space), id = 1000 + crc32(token) mod (vocab - 1000),
+// row = [CLS] ids[: max_len - 2] [SEP], zero padded.  One block per text; a thread owns a contiguous slice of the bytes,
+// counts the tokens that START in it, and after a block-wide prefix sum writes their ids at their ordinals.  ASCII only
+// (a text with a byte >= 0x80 is flagged and the caller tokenises the batch on the host).
+struct TokArgs {
+    const uint8_t* text;
+    const int64_t* off;       // [n + 1]
+    int n, max_len, vocab;    // row width = max_len (CLS / SEP included)
+    int64_t* ids;             // [n][max_len] out, 0 = padding
+    int32_t* lens;            // [n] out: tokens in the row, CLS and SEP included
+    int32_t* flags;           // [n] out: 0 = done, 1 = not ASCII
+};
+constexpr int kTokThreads = 256;
+__device__ inline bool tok_is_space(unsigned c) { return c == 0x20u || (c >= 0x09u && c <= 0x0du) || (c >= 0x1cu && c <= 0x1fu); }
+
+__global__ __launch_bounds__(kTokThreads) void hash_tokenize_kernel(TokArgs a) {
+    __shared__ unsigned crc_table[256];
+    __shared__ unsigned wsum[kTokThreads / 64];
+    __shared__ unsigned s_bad;
+    const int d = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* p = a.text + a.off[d];
+    const int64_t len = a.off[d + 1] - a.off[d];
+    {
+        unsigned c = (unsigned)tid;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        crc_table[tid] = c;
+    }
+    if (tid == 0) s_bad = 0;
+    int64_t* row = a.ids + (int64_t)d * a.max_len;
+    for (int i = tid; i < a.max_len; i += kTokThreads) row[i] = 0;
+    __syncthreads();
+    const int64_t per = (len + kTokThreads - 1) / kTokThreads;
+    const int64_t b0 = min((int64_t)tid * per, len), b1 = min(b0 + per, len);
+    auto starts_token = [&](int64_t i, unsigned c) {   // c = lower-cased byte i
+        if (bm25_is_word(c)) return i == 0 || !bm25_is_word(bm25_lower(p[i - 1]));
+        return !tok_is_space(c);
+    };
+    unsigned mine = 0, bad = 0;
+    for (int64_t i = b0; i < b1; ++i) {
+        const unsigned raw = p[i];
+        bad |= raw >> 7;
+        mine += starts_token(i, bm25_lower(raw)) ? 1u : 0u;
+    }
+    if (bad) atomicOr(&s_bad, 1u);
+    const unsigned incl = wave_scan_add(mine);
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) { a.lens[d] = 0; a.flags[d] = 1; }
+        return;
+    }
+    unsigned ord = incl - mine, total = 0;
+    for (int w = 0; w < kTokThreads / 64; ++w) {
+        if (w < (tid >> 6)) ord += wsum[w];
+        total += wsum[w];
+    }
+    const unsigned room = (unsigned)(a.max_len - 2);
+    const unsigned span = (unsigned)(a.vocab - 1000);
+    for (int64_t i = b0; i < b1 && ord < room; ++i) {
+        const unsigned c = bm25_lower(p[i]);
+        if (!starts_token(i, c)) continue;
+        unsigned crc = 0xFFFFFFFFu;
+        if (bm25_is_word(c)) {
+            int64_t j = i;
+            unsigned cj = c;
+            do {
+                crc = crc_table[(crc ^ cj) & 255u] ^ (crc >> 8);
+                ++j;
+                cj = j < len ? bm25_lower(p[j]) : 0u;
+            } while (j < len && bm25_is_word(cj));
+        } else {
+            crc = crc_table[(crc ^ c) & 255u] ^ (crc >> 8);
+        }
+        row[1 + ord] = 1000 + (int64_t)((crc ^ 0xFFFFFFFFu) % span);
+        ++ord;
+    }
+    if (tid == 0) {
+        const unsigned kept = total < room ? total : room;
+        row[0] = 101;             // CLS
+        row[1 + kept] = 102;      // SEP
+        a.lens[d] = (int32_t)kept + 2;
+        a.flags[d] = 0;
+    }
+}
+
 }  // namespace hbmrag

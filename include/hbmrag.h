@@ -321,6 +321,14 @@ HR_API int hr_filter_eval_dev(const hr_filter_term* terms, int n_terms, int64_t 
 HR_API int hr_bm25_encode_dev(const uint8_t* d_text, const int64_t* d_off, int n_docs, int sparse_dim, double k1, double b,
                        double avgdl, int cap, int32_t* d_idx, float* d_val, int32_t* d_nnz, int32_t* d_flags, void* stream);
 
+/* The hash tokenizer in front of the sentence encoder (advanced_rag/encoders.py::HashTokenizer; reference hook
+ * embedding_generator.encode_semantic, indexing.py:610-620 / :580-587) for a batch of single texts: tokens of the
+ * lower-cased text = `\w+|[^\w\s]`, id = 1000 + crc32(token) mod (vocab - 1000), row = CLS(101) ids[: max_len - 2] SEP(102),
+ * zero padded to max_len.  d_ids [n][max_len] int64, d_lens[n] (CLS and SEP included), d_flags[n]: 1 = the text holds a
+ * byte >= 0x80 (tokenise on the host).  Asynchronous on `stream`. */
+HR_API int hr_hash_tokenize_dev(const uint8_t* d_text, const int64_t* d_off, int n, int max_len, int vocab, int64_t* d_ids,
+                         int32_t* d_lens, int32_t* d_flags, void* stream);
+
 /* ---- encoder / cross-encoder forward: fused elementwise pieces -----------------
  * The GEMMs and the attention of the PyTorch-ROCm encoder forwards stay with
  * hipBLASLt / SDPA; this is the residual add + LayerNorm every post-LN BERT

@@ -503,3 +503,28 @@ def test_layer_kernels_equal_the_unfused_forward(gpu, T):
             layer.use_layer_kernels = False
         e2 = enc.module(ids, types, mask)
     assert torch.allclose(e1, e2, atol=5e-3), (e1 - e2).abs().max()
+
+
+@pytest.mark.gpu
+def test_hash_tokenizer_on_the_device_equals_the_host_tokenizer(gpu):
+    """hr_hash_tokenize_dev (csrc/text.h) against HashTokenizer.encode / .batch on the host: ids, row lengths, padding,
+    the batch width, the mask — identical tensors.  Words and digits, every ASCII punctuation and control character as a
+    token of its own, all the characters Python's \\s knows below 0x80 (incl. 0x1c - 0x1f), truncation at max_len, empty and
+    one-character texts, a word that spans many threads' slices; a batch with a non-ASCII text takes the host path."""
+    rng = np.random.default_rng(5)
+    words = [f"tok{i}" for i in range(500)] + ["MiXeD", "under_score", "42", "x"]
+    seps = [" ", ", ", ". ", "\n", "\t", " - ", "!?", "(", ")", "'s ", "\x1c", "\x1f ", "\x0b", "\x01", "~", "@#$%"]
+    texts = ["".join(str(rng.choice(words)) + str(rng.choice(seps)) for _ in range(int(n))) for n in rng.integers(1, 200, size=120)]
+    texts += ["", " ", "x", "!", "a" * 3000, "...", " lead and trail ", "".join(chr(c) for c in range(1, 128))]
+    for vocab, max_len in ((30522, 64), (5000, 16), (30522, 250), (1001 + 7, 512)):
+        tok = HashTokenizer(vocab, max_len)
+        for chunk in (texts, texts[:1], texts[120:123]):
+            got = tok.batch(chunk, device="cuda:0")
+            want = HashTokenizer(vocab, max_len).batch(chunk, device="cpu")
+            assert got[0].is_cuda
+            for g, w in zip(got, want):
+                assert g.shape == w.shape and torch.equal(g.cpu(), w), (vocab, max_len, len(chunk))
+    tok = HashTokenizer(30522, 64)
+    assert tok._batch_on_device(["plain", "ünïcode"], torch.device("cuda:0")) is None
+    got, want = tok.batch(["plain", "ünïcode"], device="cuda:0"), tok.batch(["plain", "ünïcode"], device="cpu")
+    assert all(torch.equal(g.cpu(), w) for g, w in zip(got, want))
