@@ -166,8 +166,8 @@ class _Layer(nn.Module):
                 ((hd == 32 and T <= 1024) or (hd == 64 and T <= 512)))
 
     def _fused_ok(self, x, lengths, hd, T) -> bool:
-        return (self.use_layer_kernels and self._hip_attention_ok(x, lengths, hd, T) and self.gelu in ("tanh", "erf")
-                and LayerKernels.supports(self))
+        return (self.use_layer_kernels and not getattr(_SMALL, "gemms", False) and self._hip_attention_ok(x, lengths, hd, T)
+                and self.gelu in ("tanh", "erf") and LayerKernels.supports(self))
 
     def forward_fused(self, x2, B, T, lengths, x_fr: bool = False, out_fr: bool = False):
         """The layer as three hand-written launches (csrc/encoder_layer.h, attention.h): QKV projection -> attention ->
@@ -311,6 +311,7 @@ def _seeded(module_fn, seed: int):
 
 
 _TUNED_GEMMS = None
+_SMALL = __import__("threading").local()    # .gemms = True while a small batch is being captured (see _Base._forward_replayed)
 
 
 def use_recorded_gemm_solutions() -> bool:
@@ -353,6 +354,55 @@ class _Base:
         self.batch_size = batch_size
         self.seed = seed
         self.tuned_gemms = use_recorded_gemm_solutions() if self.device.type == "cuda" else False
+
+    # A lone query (or the 20 pairs of one rerank) through a BERT-class model is ~100 launches of a few microseconds of
+    # work each: the forward is bound by launching, not by the GPU.  Such batches are captured ONCE per shape as a HIP graph
+    # (torch.cuda.CUDAGraph: the hand-written kernels launch on the capturing stream like any torch op) and replayed: one
+    # launch per forward.  Shapes are quantised (GRAPH_BATCHES texts x GRAPH_WIDTHS tokens, zero padded and masked) so that
+    # a few graphs cover the request side; larger batches (ingest, a full round of the batching front, the throughput
+    # bench) run eagerly.  Inside a replayed forward the layers use the library GEMMs, not the token-stationary layer
+    # kernels: those stream a layer's weights through ONE compute unit per 128 rows (0.12 ms per layer whatever the batch),
+    # which pays from ~4 000 rows on (tests/probes/fused_crossover.py: 2 560 rows 0.77 ms eager / fused, 0.36 ms replayed /
+    # GEMMs; 16 rows 0.69 against 0.21 ms).
+    GRAPH_BATCHES, GRAPH_WIDTHS, use_graphs, MAX_GRAPHS = (1, 2, 4, 8), (16, 32, 64), True, 24
+
+    def _forward_replayed(self, ids, types, mask):
+        if not (self.use_graphs and ids.is_cuda) or ids.shape[0] > self.GRAPH_BATCHES[-1] or ids.shape[1] > self.GRAPH_WIDTHS[-1]:
+            return None
+        import threading
+        n, w = ids.shape
+        B = next(b for b in self.GRAPH_BATCHES if b >= n)
+        W = next(x for x in self.GRAPH_WIDTHS if x >= w)
+        lock = self.__dict__.setdefault("_graph_lock", threading.Lock())
+        with lock:
+            graphs = self.__dict__.setdefault("_graphs", {})
+            g = graphs.get((B, W))
+            if g is None:
+                if len(graphs) >= self.MAX_GRAPHS:
+                    return None
+                s_ids = torch.zeros((B, W), dtype=ids.dtype, device=ids.device)
+                s_types, s_mask = torch.zeros_like(s_ids), torch.zeros((B, W), dtype=torch.bool, device=ids.device)
+                s_ids[:, 0], s_ids[:, 1], s_mask[:, :2] = CLS, SEP, True           # rows beyond n: an empty text
+                _SMALL.gemms = True
+                try:
+                    side = torch.cuda.Stream(ids.device)
+                    side.wait_stream(torch.cuda.current_stream(ids.device))
+                    with torch.cuda.stream(side):                                    # warm-up off the capturing stream
+                        for _ in range(2):
+                            self.module(s_ids, s_types, s_mask)
+                    torch.cuda.current_stream(ids.device).wait_stream(side)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        s_out = self.module(s_ids, s_types, s_mask)
+                finally:
+                    _SMALL.gemms = False
+                g = graphs[(B, W)] = (graph, s_ids, s_types, s_mask, s_out)
+            graph, s_ids, s_types, s_mask, s_out = g
+            s_ids.zero_(); s_types.zero_(); s_mask.zero_()
+            s_ids[:, 0], s_ids[:, 1], s_mask[:, :2] = CLS, SEP, True
+            s_ids[:n, :w], s_types[:n, :w], s_mask[:n, :w] = ids, types, mask
+            graph.replay()
+            return s_out[:n].clone()
 
     def load_local(self, path: str, keep_gelu: bool = False) -> "._Base":
         """Load weights from a LOCAL safetensors file with HuggingFace BERT names (never by model name).  BERT / MiniLM
@@ -429,7 +479,8 @@ class SentenceEncoder(_Base):
         self.forwards = getattr(self, "forwards", 0)
         for i in range(0, len(texts), step):
             ids, types, mask = self.tokenizer.batch(texts[i: i + step], device=self.device)
-            out.append(self.module(ids, types, mask))
+            small = self._forward_replayed(ids, types, mask)
+            out.append(small if small is not None else self.module(ids, types, mask))
             self.forwards += 1
         return torch.cat(out) if out else torch.zeros((0, self.dim), device=self.device)
 
@@ -488,6 +539,7 @@ class _CrossModule(nn.Module):
 
 class CrossEncoderModel(_Base):
     """`CrossEncoderReranker.model`: predict([(query, document), ...]) -> float32 array of relevance logits."""
+    GRAPH_BATCHES, GRAPH_WIDTHS = (1, 4, 8, 12, 16, 20, 24, 32), (64, 128, 256, 512)   # the 20 pairs of one rerank, mostly
 
     def __init__(self, config: Optional[EncoderConfig] = None, device=None, dtype=None, seed: int = 1, max_len: int = 512,
                  batch_size: int = 64):
@@ -500,7 +552,8 @@ class CrossEncoderModel(_Base):
         for i in range(0, len(pairs), self.batch_size):
             chunk = pairs[i: i + self.batch_size]
             ids, types, mask = self.tokenizer.batch([q for q, _ in chunk], [d for _, d in chunk], device=self.device)
-            out.append(self.module(ids, types, mask))
+            small = self._forward_replayed(ids, types, mask)
+            out.append(small if small is not None else self.module(ids, types, mask))
         return torch.cat(out) if out else torch.zeros(0, device=self.device)
 
     def predict(self, pairs: Sequence[Tuple[str, str]]) -> np.ndarray:

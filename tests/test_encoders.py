@@ -528,3 +528,65 @@ def test_hash_tokenizer_on_the_device_equals_the_host_tokenizer(gpu):
     assert tok._batch_on_device(["plain", "ünïcode"], torch.device("cuda:0")) is None
     got, want = tok.batch(["plain", "ünïcode"], device="cuda:0"), tok.batch(["plain", "ünïcode"], device="cpu")
     assert all(torch.equal(g.cpu(), w) for g, w in zip(got, want))
+
+
+@pytest.mark.gpu
+def test_small_batches_replay_a_captured_graph_and_match_the_eager_forward(gpu):
+    """SentenceEncoder.encode_to_device for a lone query or a handful (the query side of retrieve()): the forward is
+    captured once per quantised shape as a HIP graph and replayed.  Same embeddings as the eager forward (fp16 noise:
+    the padded width differs), one graph per shape, larger batches stay eager, and two threads may share the encoder."""
+    import threading
+    import time
+    for cfg in (EncoderConfig(), EncoderConfig(hidden=768, layers=12, heads=12, intermediate=3072)):
+        enc = SentenceEncoder(cfg, device="cuda:0", max_len=64, seed=3)
+        eager = SentenceEncoder(cfg, device="cuda:0", max_len=64, seed=3)
+        eager.use_graphs = False
+        texts = ["what is retrieval augmented generation", "short", "a b c d e f g h i j k l m n o p q r s t u v w x y z " * 2,
+                 "hybrid dense sparse fusion rerank", "x"]
+        for group in ([texts[0]], texts[:2], texts[:3], texts, [texts[2]], [texts[0]]):
+            got, want = enc.encode_to_device(group), eager.encode_to_device(group)
+            assert got.shape == want.shape and torch.allclose(got, want, atol=4e-3), (got - want).abs().max()
+        assert set(enc._graphs) <= {(b, w) for b in (1, 2, 4, 8) for w in (16, 32, 64)} and len(enc._graphs) >= 3
+        assert not getattr(eager, "_graphs", {})
+        big = enc.encode_to_device(texts * 4)                      # 20 texts: eager
+        assert big.shape[0] == 20 and torch.allclose(big[:5], enc.encode_to_device(texts), atol=4e-3)
+        # replay is what makes the lone query cheap: time both (reported, not asserted beyond "not slower by much")
+        for e in (enc, eager):
+            e.encode_to_device([texts[0]])
+        torch.cuda.synchronize()
+        t = {}
+        for name, e in (("graph", enc), ("eager", eager)):
+            t0 = time.perf_counter()
+            for _ in range(20):
+                e.encode_to_device([texts[0]])
+            torch.cuda.synchronize()
+            t[name] = (time.perf_counter() - t0) / 20 * 1e3
+        print(f"hidden {cfg.hidden} x {cfg.layers}: lone-query encode {t['graph']:.3f} ms replayed, {t['eager']:.3f} ms eager")
+        assert t["graph"] < 1.5 * t["eager"]
+        if cfg.hidden == 384:   # the 20 pairs of one rerank through the cross-encoder: replayed too, same logits
+            ce, ce_eager = CrossEncoderModel(cfg, device="cuda:0", max_len=128, seed=5), CrossEncoderModel(cfg, device="cuda:0", max_len=128, seed=5)
+            ce_eager.use_graphs = False
+            pairs = [(texts[0], texts[i % 5] + f" document {i} " + "filler words " * (i % 7)) for i in range(20)]
+            for group in (pairs, pairs[:1], pairs[:7]):
+                a_, b_ = ce.predict_to_device(group), ce_eager.predict_to_device(group)
+                assert a_.shape == b_.shape and torch.allclose(a_.float(), b_.float(), atol=3e-3), (a_ - b_).abs().max()
+            assert ce._graphs and not getattr(ce_eager, "_graphs", {})
+            ce.predict(pairs); ce_eager.predict(pairs)
+            torch.cuda.synchronize()
+            for name, m in (("replayed", ce), ("eager", ce_eager)):
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    m.predict_to_device(pairs)
+                torch.cuda.synchronize()
+                print(f"cross-encoder, 20 pairs: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms {name}")
+        out = {}
+
+        def worker(k):
+            out[k] = [enc.encode_to_device([texts[k % 5]]).clone() for _ in range(10)]
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        torch.cuda.synchronize()
+        for k in range(4):
+            ref = eager.encode_to_device([texts[k % 5]])
+            assert all(torch.allclose(v, ref, atol=4e-3) for v in out[k])
