@@ -392,7 +392,9 @@ class _Base:
                             self.module(s_ids, s_types, s_mask)
                     torch.cuda.current_stream(ids.device).wait_stream(side)
                     graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph):
+                    # thread_local: other threads of the process (the batching front's searches, an ingest) may allocate
+                    # device memory while this one captures
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         s_out = self.module(s_ids, s_types, s_mask)
                 finally:
                     _SMALL.gemms = False
