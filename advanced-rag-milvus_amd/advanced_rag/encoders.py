@@ -358,13 +358,13 @@ class _Base:
     # A lone query (or the 20 pairs of one rerank) through a BERT-class model is ~100 launches of a few microseconds of
     # work each: the forward is bound by launching, not by the GPU.  Such batches are captured ONCE per shape as a HIP graph
     # (torch.cuda.CUDAGraph: the hand-written kernels launch on the capturing stream like any torch op) and replayed: one
-    # launch per forward.  Shapes are quantised (GRAPH_BATCHES texts x GRAPH_WIDTHS tokens, zero padded and masked) so that
+    # launch per forward.  Shapes are quantised (GRAPH_BATCHES texts x GRAPH_WIDTHS tokens — up to a round of the batching front —, zero padded and masked) so that
     # a few graphs cover the request side; larger batches (ingest, a full round of the batching front, the throughput
     # bench) run eagerly.  Inside a replayed forward the layers use the library GEMMs, not the token-stationary layer
     # kernels: those stream a layer's weights through ONE compute unit per 128 rows (0.12 ms per layer whatever the batch),
     # which pays from ~4 000 rows on (tests/probes/fused_crossover.py: 2 560 rows 0.77 ms eager / fused, 0.36 ms replayed /
     # GEMMs; 16 rows 0.69 against 0.21 ms).
-    GRAPH_BATCHES, GRAPH_WIDTHS, use_graphs, MAX_GRAPHS = (1, 2, 4, 8), (16, 32, 64), True, 24
+    GRAPH_BATCHES, GRAPH_WIDTHS, use_graphs, MAX_GRAPHS = (1, 2, 4, 8, 16, 32, 64), (16, 32, 64), True, 24
 
     def _forward_replayed(self, ids, types, mask):
         if not (self.use_graphs and ids.is_cuda) or ids.shape[0] > self.GRAPH_BATCHES[-1] or ids.shape[1] > self.GRAPH_WIDTHS[-1]:

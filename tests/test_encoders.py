@@ -546,10 +546,13 @@ def test_small_batches_replay_a_captured_graph_and_match_the_eager_forward(gpu):
         for group in ([texts[0]], texts[:2], texts[:3], texts, [texts[2]], [texts[0]]):
             got, want = enc.encode_to_device(group), eager.encode_to_device(group)
             assert got.shape == want.shape and torch.allclose(got, want, atol=4e-3), (got - want).abs().max()
-        assert set(enc._graphs) <= {(b, w) for b in (1, 2, 4, 8) for w in (16, 32, 64)} and len(enc._graphs) >= 3
+        assert set(enc._graphs) <= {(b, w) for b in (1, 2, 4, 8, 16, 32, 64) for w in (16, 32, 64)} and len(enc._graphs) >= 3
         assert not getattr(eager, "_graphs", {})
-        big = enc.encode_to_device(texts * 4)                      # 20 texts: eager
-        assert big.shape[0] == 20 and torch.allclose(big[:5], enc.encode_to_device(texts), atol=4e-3)
+        n_graphs = len(enc._graphs)
+        big = enc.encode_to_device(texts * 20, batch_size=100)     # 100 texts in one batch: eager
+        assert big.shape[0] == 100 and len(enc._graphs) == n_graphs and torch.allclose(big[:5], enc.encode_to_device(texts), atol=4e-3)
+        mid = enc.encode_to_device(texts * 8)                      # 40 texts: the 64-text graph
+        assert torch.allclose(mid, eager.encode_to_device(texts * 8), atol=4e-3) and len(enc._graphs) == n_graphs + 1
         # replay is what makes the lone query cheap: time both (reported, not asserted beyond "not slower by much")
         for e in (enc, eager):
             e.encode_to_device([texts[0]])
