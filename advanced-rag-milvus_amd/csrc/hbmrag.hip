@@ -1646,8 +1646,9 @@ static int hybrid_scan_phases(hr_index* h, const float* d_q, const int64_t* d_q_
     if (max_q_nnz < 0 || max_q_nnz > HR_MAX_QUERY_NNZ) return fail(h, HR_ELIMIT, "query nnz exceeds HR_MAX_QUERY_NNZ");
     std::shared_lock<std::shared_mutex> lk(h->rw);
     DeviceGuard dg(h->device);
-    Workspace *wd, *wsp;
+    Workspace *wd = nullptr, *wsp = nullptr;
     HR_TRY(slot_workspaces(h, slot, &wd, &wsp));
+    if (!wd || !wsp) return fail(h, HR_ENOMEM, "no workspace for slot %d", slot);
     std::lock_guard<std::mutex> slot_held(wd->mu);
     hipStream_t s = (hipStream_t)stream;
     const int C = candidate_groups_for_k(k);
@@ -1684,8 +1685,9 @@ int hr_hybrid_finish_dev(hr_index* h, const float* d_q, const int64_t* d_q_indpt
     if (!d_q || !d_q_indptr || !d_ids || !d_scores) return fail(h, HR_EINVAL, "null buffer");
     std::shared_lock<std::shared_mutex> lk(h->rw);
     DeviceGuard dg(h->device);
-    Workspace *wd, *wsp;
+    Workspace *wd = nullptr, *wsp = nullptr;
     HR_TRY(slot_workspaces(h, slot, &wd, &wsp));
+    if (!wd || !wsp) return fail(h, HR_ENOMEM, "no workspace for slot %d", slot);
     std::lock_guard<std::mutex> slot_held(wd->mu);
     hipStream_t s = (hipStream_t)stream;
     const int C = candidate_groups_for_k(k);
