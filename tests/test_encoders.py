@@ -233,6 +233,11 @@ def test_fused_embedding_layernorm_matches_the_unfused_fp16_ops(gpu, n_seq, T, h
     h = (word[ids] + pos[:T][None]) + seg[types]                      # fp16, rounded after each add
     want = torch.nn.functional.layer_norm(h.float(), (hidden,), gamma.float(), beta.float(), 1e-12)
     assert torch.allclose(got.float(), want, atol=2e-3, rtol=2e-3), (got.float() - want).abs().max()
+    # and against plain fp32 PyTorch on the fp16-rounded tables (no fp16 rounding between the adds): the kernel's two fp16
+    # roundings of the sum (|h| < 4: half an ulp = 1e-3 each) pass through the LayerNorm's gain of ~1.5
+    h32 = word.float()[ids] + pos.float()[:T][None] + seg.float()[types]
+    want32 = torch.nn.functional.layer_norm(h32, (hidden,), gamma.float(), beta.float(), 1e-12)
+    assert torch.allclose(got.float(), want32, atol=6e-3, rtol=2e-3), (got.float() - want32).abs().max()
     wild_i, wild_t = ids.clone(), types.clone()
     wild_i[0, 0], wild_i[-1, -1], wild_t[0, 0] = -5, V + 9, 7
     ref_i, ref_t = wild_i.clamp(0, V - 1), wild_t.clamp(0, 1)
