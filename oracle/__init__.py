@@ -271,3 +271,101 @@ def cpu_hybrid(Xn32, csr, Q, q_csr, top_k: int = 20, wa: float = 0.7, wb: float 
         ids, sc, _ = rrf_py(di[b], [i for i in si[b] if i >= 0], (), wa, wb)
         out.append((ids[:top_k], sc[:top_k]))
     return out
+
+
+# ---- filter expressions (test infrastructure, like everything in this package) ----------------------------------------
+# What HybridRetriever._build_filter_expression emits (reference retrieval.py:565-632): `field OP literal` terms joined by
+# " and ", OP in {>=, <=, >, <, ==, !=}, literals = integers, floats, True / False, or "double-quoted strings" with \\ and
+# \" escapes.  Milvus' evaluation of them is third-party and absent (unpinned); the semantics below are
+# the build's, written out explicitly so that the device kernel and the product's host evaluator are checked against a
+# statement that does not lean on numpy's type promotion:
+#   * FLOAT fields (float32 columns) compare against the literal ROUNDED TO float32;
+#   * INT64 fields compare against an integer literal as integers (a bool counts as 0 / 1), against a float literal as float64;
+#   * VARCHAR fields compare by the UTF-8 bytes of the strings (= by code point); a string literal on a numeric field or a
+#     number on a string field is an error.
+def _filter_terms(expr: str):
+    """-> [(field, op, literal)] by a character scanner (no regular expressions): literal is str | bool | int | float."""
+    i, n, out = 0, len(expr), []
+    ops = (">=", "<=", "==", "!=", ">", "<")
+    while True:
+        while i < n and expr[i].isspace():
+            i += 1
+        j = i
+        while j < n and (expr[j].isalnum() or expr[j] == "_"):
+            j += 1
+        if j == i:
+            raise ValueError(f"field name expected at {i} in {expr!r}")
+        field = expr[i:j]
+        i = j
+        while i < n and expr[i].isspace():
+            i += 1
+        op = next((o for o in ops if expr.startswith(o, i)), None)
+        if op is None:
+            raise ValueError(f"operator expected at {i} in {expr!r}")
+        i += len(op)
+        while i < n and expr[i].isspace():
+            i += 1
+        if i < n and expr[i] == '"':
+            i += 1
+            buf = []
+            while True:
+                if i >= n:
+                    raise ValueError(f"unterminated string in {expr!r}")
+                ch = expr[i]
+                if ch == "\\" and i + 1 < n:
+                    buf.append(expr[i + 1])
+                    i += 2
+                elif ch == '"':
+                    i += 1
+                    break
+                else:
+                    buf.append(ch)
+                    i += 1
+            lit = "".join(buf)
+        else:
+            j = expr.find(" and ", i)
+            raw = (expr[i:] if j < 0 else expr[i:j]).strip()
+            i = n if j < 0 else j
+            if raw in ("True", "true"):
+                lit = True
+            elif raw in ("False", "false"):
+                lit = False
+            else:
+                try:
+                    lit = int(raw)
+                except ValueError:
+                    lit = float(raw)       # ValueError for anything else
+        out.append((field, op, lit))
+        while i < n and expr[i].isspace():
+            i += 1
+        if i >= n:
+            return out
+        if not expr.startswith("and", i):
+            raise ValueError(f"'and' expected at {i} in {expr!r}")
+        i += 3
+
+
+def filter_mask(expr: str, columns, n_rows: int) -> np.ndarray:
+    """Boolean row predicate of a conjunctive filter expression over `columns` (name -> numpy array of n_rows)."""
+    import operator
+    cmp = {">=": operator.ge, "<=": operator.le, ">": operator.gt, "<": operator.lt, "==": operator.eq, "!=": operator.ne}
+    keep = np.ones(n_rows, dtype=bool)
+    for field, op, lit in _filter_terms(expr):
+        if field not in columns:
+            raise ValueError(f"unknown filter field: {field}")
+        col = np.asarray(columns[field])
+        if col.dtype.kind in "US":
+            if not isinstance(lit, str):
+                raise ValueError(f"field {field} holds strings; got {lit!r}")
+            a = np.char.encode(col, "utf-8") if col.dtype.kind == "U" else col
+            keep &= cmp[op](a, np.bytes_(lit.encode("utf-8")))
+        else:
+            if isinstance(lit, str):
+                raise ValueError(f"field {field} is numeric; got string {lit!r}")
+            if col.dtype.kind == "f":
+                keep &= cmp[op](col.astype(np.float32), np.float32(lit))
+            elif isinstance(lit, float):
+                keep &= cmp[op](col.astype(np.float64), np.float64(lit))
+            else:
+                keep &= cmp[op](col.astype(np.int64), np.int64(int(lit)))
+    return keep

@@ -1,5 +1,6 @@
 """Filter expressions evaluated on the device (hr_filter_eval_dev over HBM-resident columns, device_filters.py) against
-the numpy restatement of the same semantics (filters.evaluate), bit for bit, at 1M rows with real payload columns:
+the oracle's statement of the semantics (oracle.filter_mask; the product's host evaluator filters.evaluate is held to it
+as well), bit for bit, at 1M rows with real payload columns:
 every expression of golden g4 (what the reference's _build_filter_expression emits, retrieval.py:565-632), quoted
 values containing operators / ' and ' / escaped quotes, prefix ties that need the full strings, tombstones."""
 import asyncio
@@ -78,9 +79,10 @@ def test_device_filter_equals_numpy_restatement_at_1m_rows(gpu):
         m.finalize()
         host_cols = m._columns()
         for expr in EXPRS:
-            want = F.evaluate(expr, host_cols, N)
+            want = oracle.filter_mask(expr, host_cols, N)       # the checker is the oracle's statement of the semantics ...
             got = np.unpackbits(m._global_device_mask(expr).cpu().numpy(), bitorder="little")[:N].astype(bool)
             assert np.array_equal(got, want), (expr, int(got.sum()), int(want.sum()))
+            assert np.array_equal(F.evaluate(expr, host_cols, N), want), expr   # ... which the product's host evaluator meets too
         assert m._dev_filters.stats["undecided_rows"] > 0            # the prefix-tie path ran
         assert m._dev_filters.stats["uploaded_bytes"] - up0 < 10 * N * 8   # each column went up once (keys: 16 B/row)
         # error behaviour of the restatement is kept

@@ -123,6 +123,26 @@ def test_filter_expression_evaluates_to_row_mask():
     expr = hr._build_filter_expression({"timestamp": {"$gte": "2024-01-01", "$lt": "2025-01-01"}, "chunk_index": {"$ne": 2}})
     assert filters.evaluate(expr, cols, 4).tolist() == [False, True, False, False]
     assert filters.pack(np.array([1, 0, 1, 1, 0, 0, 0, 0, 1], bool)).tolist() == [0b00001101, 0b1]
+    # the host evaluator against the oracle's explicit statement of the semantics (float32-rounded literals on FLOAT fields,
+    # integer or float64 comparison on INT64 fields, UTF-8 byte order on strings), over every expression golden g4 holds
+    import oracle
+    rng = np.random.default_rng(3)
+    n = 4000
+    pool = ['doc"123', "a\\b", "a >= b", "x and y", 'q"uo\\te', "", "0123456789abcdef-tail-A", "0123456789abcdef-tail-B", "doc9", "doc95", "ünï"]
+    big = {"chunk_index": rng.integers(0, 12, n), "token_count": rng.integers(0, 2000, n),
+           "entropy": (rng.integers(0, 11, n) / 10).astype(np.float32), "redundancy": (rng.integers(0, 11, n) / 10).astype(np.float32),
+           "domain_density": rng.random(n).astype(np.float32), "doc_id": np.array([pool[i] for i in rng.integers(0, len(pool), n)]),
+           "chunk_id": np.array([f"d::{i % 3}::abcd123{i % 10}" for i in range(n)]),
+           "timestamp": np.array([f"202{i % 6}-0{1 + i % 9}-1{i % 9}" for i in range(n)])}
+    exprs = [c["expr"] for c in gold("g4_filters.json") if c.get("expr")]
+    exprs += ['doc_id == "ünï"', "chunk_index == true and entropy != 0.30000001192092896", "token_count >= 1e3", "chunk_index >= 2.5",
+              'doc_id < "0123456789abcdef-tail-B" and doc_id >= "0123456789abcdef"', "entropy >= 1"]
+    for e in exprs:
+        assert np.array_equal(filters.evaluate(e, big, n), oracle.filter_mask(e, big, n)), e
+    for bad in ('doc_id == 5', 'chunk_index == "x"', "nofield > 1", 'doc_id == "open'):
+        for fn in (filters.evaluate, oracle.filter_mask):
+            with pytest.raises(ValueError):
+                fn(bad, big, n)
     with pytest.raises(ValueError):
         filters.evaluate('entropy >= "x"', cols, 4)
     with pytest.raises(ValueError):
