@@ -25,6 +25,12 @@ def row_id(r: int) -> str:
     return f"doc{r // 10}::{r % 10}::{r:08x}"
 
 
+def load_g13():
+    """G13 = the same chain at BASELINE config 2's size (100 000 x 384 fp32; tests/golden/gen_golden_g13.py)."""
+    with open(os.path.join(GOLD, "g13_retrieve_c2.json")) as f:
+        return json.load(f)
+
+
 def inputs(g=None):
     """-> (g, X float32 [N,D], (indptr, idx, val) CSR of the sparse rows, Q float32 [8,D], SQ [(idx, val)] * 8)."""
     g = g or load()

@@ -128,6 +128,22 @@ def test_g5_retrieve_on_device_fp16_reports_rank_flips(gpu, long_timeout):
     assert identical == 16 and not flips, flips
 
 
+def test_g13_retrieve_on_device_at_config2_size_matches_reference(gpu, long_timeout):
+    """G13: the reference's retrieve() at 100 000 x 384 fp32 (BASELINE config 2's size) through the HIP path — fp32 shard,
+    dense-only and hybrid, all 16 runs: ids, float64 fused scores bit for bit, method tags."""
+    g, X, csr, Q, SQ = g5_data.inputs(g5_data.load_g13())
+    for with_sparse in (False, True):
+        mgr = _g5_manager("float32", X, csr, with_sparse)
+        try:
+            for run in (r for r in g["runs"] if r["with_sparse"] == with_sparse):
+                out = _run_g5(mgr, Q, SQ, run)
+                assert [o["id"] for o in out] == run["ids"], (with_sparse, run["query"])
+                assert [float(o["score"]).hex() for o in out] == run["scores"]
+                assert [sorted(o["retrieval_methods"]) for o in out] == run["methods"]
+        finally:
+            asyncio.run(mgr.close())
+
+
 # --------------------------------------------------------------------------- g1 / g2
 def test_g1_every_reference_fusion_case_through_the_rrf_kernel(gpu):
     cases = gold("g1_fuse.json")

@@ -135,6 +135,27 @@ def test_oracle_search_chain_reproduces_the_references_retrieve_on_config1():
         assert [sorted(n for bit, n in enumerate(names) if (int(m) >> bit) & 1) for m in methods] == run["methods"]
 
 
+def test_oracle_search_chain_reproduces_the_references_retrieve_at_config2_size():
+    """G13 (tests/golden/gen_golden_g13.py): the reference's HybridRetriever.retrieve over an exact numpy FLAT collection of
+    100 000 x 384 fp32 rows + 100-term sparse rows (BASELINE config 2's size: seven 16 384-doc ranges, thousands of
+    candidate groups), 8 queries, dense-only and hybrid -> the oracle chain gives the same ids, float64 fused scores (bit
+    for bit) and method tags."""
+    import g5_data
+    g, X, (ptr, idx, val), Q, SQ = g5_data.inputs(g5_data.load_g13())
+    assert (g["N"], g["D"], len(g["runs"])) == (100_000, 384, 16)
+    kp, top_k = 40, 20
+    di, _ = oracle.dense_search(X, Q, kp, oracle.COSINE)
+    si, _ = oracle.sparse_search(ptr, idx, val, SQ, kp, 0.2)
+    names = ("semantic", "sparse", "domain")
+    for run in g["runs"]:
+        q = run["query"]
+        sparse_list = si[q][si[q] >= 0] if run["with_sparse"] else ()
+        ids, scores, methods = oracle.rrf(di[q], sparse_list, (), 0.7, 0.3, 0.2, 60)
+        assert [g5_data.row_id(int(r)) for r in ids[:top_k]] == run["ids"], (run["with_sparse"], q)
+        assert [float(s).hex() for s in scores[:top_k]] == run["scores"]
+        assert [sorted(n for bit, n in enumerate(names) if (int(m) >> bit) & 1) for m in methods[:top_k]] == run["methods"]
+
+
 # --------------------------------------------------------------------------- G11 / G12 (round 4)
 NAMES3 = ("semantic", "sparse", "domain")
 
