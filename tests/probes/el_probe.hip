@@ -14,7 +14,10 @@ using namespace hbmrag;
 int main(int argc, char** argv) {
     const int64_t M = argc > 1 ? atoll(argv[1]) : 327680;
     const int reps = argc > 2 ? atoi(argv[2]) : 20;
-    constexpr int H = 384, I = 1536, HS = 12, IS = 48, TT = 2;
+#ifndef EL_LINEAR_TT
+#define EL_LINEAR_TT 2
+#endif
+    constexpr int H = 384, I = 1536, HS = 12, IS = 48, TT = 2, LTT = EL_LINEAR_TT;   // LTT: token tiles per wave of the linear kernel
     const size_t stream_halves = (size_t)(HS + 2 * IS) * (H / 16) * 512;
     std::vector<_Float16> hw(stream_halves), ha((size_t)M * H);
     srand(1);
@@ -30,12 +33,13 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dx, ha.data(), (size_t)M * H * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dt, tb.data(), tb.size() * 4, hipMemcpyHostToDevice));
     CK(hipFuncSetAttribute((const void*)encoder_tail_kernel<HS, IS, TT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CK(hipFuncSetAttribute((const void*)linear_rows_kernel<HS, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute((const void*)linear_rows_kernel<HS, LTT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     TailArgs a{}; a.a = da; a.x = dx; a.out = dout; a.wstream = (const chunk_t*)dw; a.tables = dt; a.M = M; a.eps = 1e-12f; a.x_fr = a.out_fr = argc > 3 ? atoi(argv[3]) : 1;
     LinearArgs l{}; l.x = dx; l.w = (const chunk_t*)dw; l.bias = dt; l.out = dqkv; l.M = M; l.out_stride = 3 * H; l.N = 3 * H; l.x_fr = argc > 3 ? atoi(argv[3]) : 1;
     const size_t lds_t = (size_t)kElRingStages * 2 * HS * 1024 + (size_t)(6 * H + I) * 4;
     const size_t lds_l = (size_t)(kElRingStages + 1) * 2 * HS * 1024 + (size_t)3 * H * 4;
     const unsigned blocks = (unsigned)((M + 64 * TT - 1) / (64 * TT));
+    const unsigned blocks_l = (unsigned)((M + 64 * LTT - 1) / (64 * LTT));
 #ifdef EL_STAMP
     unsigned long long* dst;
     CK(hipMalloc(&dst, (size_t)blocks * 8 * 8));
@@ -45,13 +49,13 @@ int main(int argc, char** argv) {
     for (int which = 0; which < 2; ++which) {
         for (int r = 0; r < 3; ++r) {
             if (which == 0) hipLaunchKernelGGL((encoder_tail_kernel<HS, IS, TT, false>), dim3(blocks), dim3(256), lds_t, 0, a);
-            else hipLaunchKernelGGL((linear_rows_kernel<HS, TT>), dim3(blocks), dim3(256), lds_l, 0, l);
+            else hipLaunchKernelGGL((linear_rows_kernel<HS, LTT>), dim3(blocks_l), dim3(256), lds_l, 0, l);
         }
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
         for (int r = 0; r < reps; ++r) {
             if (which == 0) hipLaunchKernelGGL((encoder_tail_kernel<HS, IS, TT, false>), dim3(blocks), dim3(256), lds_t, 0, a);
-            else hipLaunchKernelGGL((linear_rows_kernel<HS, TT>), dim3(blocks), dim3(256), lds_l, 0, l);
+            else hipLaunchKernelGGL((linear_rows_kernel<HS, LTT>), dim3(blocks_l), dim3(256), lds_l, 0, l);
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;

@@ -416,7 +416,7 @@ def _ref_layer_tail(a, x, layer, gelu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows", [1, 127, 128, 129, 1000, 4096 + 77])
+@pytest.mark.parametrize("rows", [1, 127, 128, 129, 1000, 4096 + 77, 65536, 65536 + 300 + 13])   # from 65 536 rows: 4 token tiles per wave
 def test_linear_rows_kernel_matches_fp32(gpu, rows):
     """hr_linear_rows_f16_dev (K = 384; N = 1152 the QKV projection, 768 keys + values, 32 the smallest) against an fp32
     matmul of the same fp16-rounded operands; ragged row counts, a strided output."""
